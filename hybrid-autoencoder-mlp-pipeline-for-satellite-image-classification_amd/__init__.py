@@ -1,0 +1,10 @@
+"""MI355X-native drop-in for the conv-autoencoder + MLP training path of the reference notebook.
+
+Public surface mirrors the notebook: ``Encoder``, ``Decoder``,
+``SupervisedAutoencoder``, ``MLP``, ``extract_features`` plus the ``fit``/``evaluate`` entry points
+that restate its inline loops.  All arithmetic runs in hand-written gfx950 HIP kernels behind the
+C ABI declared in ``include/eae.h``.
+"""
+from .modules import Encoder, Decoder, SupervisedAutoencoder, MLP  # noqa: F401
+
+__all__ = ["Encoder", "Decoder", "SupervisedAutoencoder", "MLP"]

@@ -1,0 +1,214 @@
+"""Pin the CPU oracle (oracle/ae_numpy.py) to the golden vectors produced by the reference's own classes.
+
+Tolerances: fp32 oracle vs fp32 reference <= 1e-5 abs on activations (measured fp32 noise floor ~1e-6,
+SURVEY.md 8c); gradients relative 1e-4 of the tensor's abs-max."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from helpers import ae_state_np, mlp_state_np, digest_close
+from oracle import ae_numpy as O
+
+
+def _relerr(a, b):
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+def test_init_matches_reference_seed(golden):
+    g = golden("init_digest.npz")
+    for latent in (64, 128):
+        sd = ae_state_np(latent, perturb=False)
+        for k, v in sd.items():
+            d, s = gu.tensor_digest(v)
+            assert np.array_equal(d, g[f"ae{latent}/{k}/digest"]), k
+            assert np.array_equal(s, g[f"ae{latent}/{k}/sample"]), k
+    sd = mlp_state_np(perturb=False)
+    for k, v in sd.items():
+        d, s = gu.tensor_digest(v)
+        assert np.array_equal(d, g[f"mlp64/{k}/digest"]), k
+
+
+@pytest.mark.parametrize("b", [2, 8])
+def test_ae_forward_train_eval(golden, b):
+    g = golden(f"ae_fwd_bwd_b{b}.npz")
+    p = ae_state_np()
+    x, y = g["x"], g["labels"]
+    out = O.ae_forward(p, x, train=False)
+    assert np.abs(out["x_hat"] - g["eval_x_hat"]).max() < 1e-5
+    assert np.abs(out["logits"] - g["eval_logits"]).max() < 2e-5
+    assert np.abs(out["z"] - g["eval_z"]).max() < 2e-5
+    out = O.ae_forward(p, x, train=True)
+    assert np.abs(out["x_hat"] - g["x_hat"]).max() < 1e-5
+    assert np.abs(out["logits"] - g["logits"]).max() < 5e-5
+    assert np.abs(out["z"] - g["z"]).max() < 5e-5
+    loss, l_r, l_c = O.ae_loss(out, x, y, float(g["alpha"]))
+    assert abs(loss - g["loss"]) < 1e-5 * max(1, abs(g["loss"]))
+    assert abs(l_r - g["loss_recon"]) < 1e-6
+    for k, v in out["new_buffers"].items():
+        np.testing.assert_allclose(v, g[f"buf/{k}"], rtol=1e-5, atol=1e-6)
+
+
+def test_ae_intermediates(golden):
+    g = golden("ae_fwd_bwd_b2.npz")
+    p = ae_state_np()
+    out = O.ae_forward(p, g["x"], train=True)
+    c = out["cache"]
+    np.testing.assert_allclose(c["enc0"][1], g["inter/enc.encoder.0"], atol=1e-5)       # conv1 raw
+    np.testing.assert_allclose(np.maximum(c["enc0"][3], 0), g["inter/enc.encoder.2"], atol=1e-5)
+    np.testing.assert_allclose(c["enc1"][1], g["inter/enc.encoder.3"], atol=2e-5)
+    np.testing.assert_allclose(c["enc3"][1], g["inter/enc.encoder.9"], atol=5e-5)
+    np.testing.assert_allclose(c["dec0"][1], g["inter/dec.decoder.1"], atol=5e-5)       # deconv1 raw
+    np.testing.assert_allclose(c["dec1"][1], g["inter/dec.decoder.4"], atol=5e-5)
+    np.testing.assert_allclose(c["dec3"][1], g["inter/dec.decoder.10"], atol=5e-5)      # pre-sigmoid
+
+
+def test_ae_gradients_full(golden):
+    g = golden("ae_fwd_bwd_b8.npz")
+    p = ae_state_np()
+    x, y = g["x"], g["labels"]
+    out = O.ae_forward(p, x, train=True)
+    gr = O.ae_backward(p, out, x, y, float(g["alpha"]))
+    assert _relerr(gr["dz"], g["dz"]) < 1e-4
+    n = 0
+    for k in g.files:
+        if not k.startswith("grad/"):
+            continue
+        name = k[5:]
+        ref = g[k]
+        # conv biases in front of BatchNorm have analytically-zero gradients (pure rounding noise in torch)
+        if np.abs(ref).max() < 1e-6:
+            assert np.abs(gr[name]).max() < 1e-5, name
+        else:
+            assert _relerr(gr[name], ref) < 2e-4, (name, _relerr(gr[name], ref))
+        n += 1
+    assert n == 38
+
+
+@pytest.mark.parametrize("b", [32, 48, 56])
+def test_ae_big_and_short_batches(golden, b):
+    g = golden(f"ae_fwd_bwd_b{b}.npz")
+    p = ae_state_np()
+    x, y = gu.make_images(b, int(g["seed"]))
+    assert np.array_equal(y, g["labels"])
+    out = O.ae_forward(p, x, train=True)
+    np.testing.assert_allclose(out["x_hat"].ravel()[::7], g["x_hat"], atol=1e-5)
+    assert np.abs(out["logits"] - g["logits"]).max() < 5e-5
+    loss, _, _ = O.ae_loss(out, x, y, float(g["alpha"]))
+    assert abs(loss - g["loss"]) < 2e-5 * max(1, abs(g["loss"]))
+    gr = O.ae_backward(p, out, x, y, float(g["alpha"]))
+    for k in g.files:
+        if k.startswith("gradd/") and k.endswith("/digest"):
+            name = k[6:-7]
+            if g[k][1] < 1e-5:
+                continue
+            # The fp32 backward of this network is ill-conditioned at larger batches: the reference's OWN
+            # fp32 gradients differ from an fp64 run of the same classes by up to 4.7e-2 of abs-max
+            # (measured at b=56), so two correct fp32 implementations only agree to ~1e-2 here.
+            digest_close(gr[name], g[k], g[f"gradd/{name}/sample"], rtol=3e-3)
+
+
+def test_ae_eval_b1_and_latent128(golden):
+    g = golden("ae_eval_b1.npz")
+    out = O.ae_forward(ae_state_np(), g["x"], train=False)
+    assert np.abs(out["x_hat"] - g["eval_x_hat"]).max() < 1e-5
+    assert np.abs(out["logits"] - g["eval_logits"]).max() < 2e-5
+    g = golden("ae_latent128_b8.npz")
+    out = O.ae_forward(ae_state_np(128), g["x"], train=True)
+    assert np.abs(out["x_hat"] - g["x_hat"]).max() < 1e-5
+    assert np.abs(out["z"] - g["z"]).max() < 5e-5
+    l_c, _ = O.cross_entropy(out["logits"], g["labels"])
+    l_r, _ = O.mse(out["x_hat"], g["x"])
+    assert abs(l_c - g["ce"]) < 1e-5 and abs(l_r - g["mse"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag,head", [("joint", True), ("recon", False)])
+def test_ae_adam_trajectory(golden, tag, head):
+    g = golden(f"ae_adam5_{tag}_b8.npz")
+    p = ae_state_np()
+    st = O.new_adam_state()
+    alpha = float(g["alpha"]) if head else 1.0
+    losses = []
+    for step in range(5):
+        x, y = gu.make_images(8, 200 + step)
+        loss, *_ = O.ae_train_step(p, st, x, y, alpha, float(g["lr"]), head=head)
+        losses.append(loss)
+    np.testing.assert_allclose(np.array(losses), g["losses"], rtol=2e-4)
+    for k in g.files:
+        if k.startswith("buf/"):
+            name = k[4:]
+            if name.endswith("num_batches_tracked"):
+                assert int(p[name]) == int(g[k])
+            elif name.endswith("running_mean"):
+                # conv biases in front of BN get noise-only gradients; Adam turns noise into +-lr steps, which
+                # shift the batch mean (hence running_mean) by up to ~lr per step in either implementation.
+                np.testing.assert_allclose(p[name], g[k], rtol=1e-3, atol=5 * 5e-3)
+            else:   # running_var: Adam's sign-like early steps amplify fp32 noise (see above)
+                np.testing.assert_allclose(p[name], g[k], rtol=1e-2, atol=1e-5)
+    # Adam's sign-like first steps amplify rounding noise on ~zero gradients: compare digests loosely
+    # and only on tensors whose gradients are not analytically zero.
+    for k in g.files:
+        if k.startswith("final/") and k.endswith("/digest"):
+            name = k[6:-7]
+            if "running" in name or "num_batches" in name:
+                continue
+            is_prebn_bias = name.endswith(".bias") and (
+                name.startswith("enc.encoder.") and name.split(".")[2] in ("0", "3", "6", "9")
+                or name.startswith("dec.decoder.") and name.split(".")[2] in ("1", "4", "7"))
+            if is_prebn_bias or (not head and name.startswith("classifier")):
+                continue
+            d, s = gu.tensor_digest(p[name])
+            assert abs(d[1] - g[k][1]) < 2e-3 * max(1.0, g[k][1]), (name, d, g[k])
+            err = np.abs(s - g[f"final/{name}/sample"])
+            assert np.mean(err < 1e-3) > 0.98, (name, err.max())
+
+
+def test_mlp_forward_backward(golden):
+    g = golden("mlp_fwd_bwd_b64.npz")
+    p = mlp_state_np()
+    out = O.mlp_forward(p, g["x"], train=False)
+    assert np.abs(out["logits"] - g["eval_logits"]).max() < 1e-5
+    out = O.mlp_forward(p, g["x"], train=True, drop_mask=g["drop_mask"])
+    assert np.abs(out["logits"] - g["logits"]).max() < 2e-5
+    loss, gr = O.mlp_backward(p, out, g["labels"])
+    assert abs(loss - g["loss"]) < 1e-5
+    for k in g.files:
+        if k.startswith("grad/"):
+            if np.abs(g[k]).max() < 1e-6:       # Linear bias in front of BatchNorm1d: analytically zero
+                assert np.abs(gr[k[5:]]).max() < 1e-5, k
+            else:
+                assert _relerr(gr[k[5:]], g[k]) < 2e-4, k
+    for k, v in out["new_buffers"].items():
+        np.testing.assert_allclose(v, g[f"buf/{k}"], rtol=1e-5, atol=1e-6)
+
+
+def test_mlp_adam_trajectory(golden):
+    g = golden("mlp_adam5.npz")
+    p = mlp_state_np()
+    st = O.new_adam_state()
+    losses, correct = [], []
+    for step, b in enumerate((64, 64, 64, 64, 48)):
+        x, y = gu.make_latents(b, 400 + step)
+        loss, out, _ = O.mlp_train_step(p, st, x, y, float(g["lr"]), drop_mask=g[f"mask{step}"])
+        losses.append(loss)
+        correct.append(int((out["logits"].argmax(1) == y).sum()))
+    np.testing.assert_allclose(np.array(losses), g["losses"], rtol=1e-4)
+    assert correct == list(g["correct"])
+    for k in g.files:
+        if k.startswith("final/"):
+            name = k[6:]
+            if name.endswith("num_batches_tracked"):
+                assert int(p[name]) == int(g[k])
+            else:
+                np.testing.assert_allclose(p[name], g[k], rtol=2e-3, atol=2e-5)
+
+
+def test_extract_features_oracle(golden):
+    g = golden("extract_features.npz")
+    p = ae_state_np()
+    zs, ys = [], []
+    for i, b in enumerate((8, 5)):
+        x, y = gu.make_images(b, 500 + i)
+        zs.append(O.ae_forward(p, x, train=False, head=False)["z"])
+        ys.append(y)
+    np.testing.assert_allclose(np.concatenate(zs), g["X"], atol=2e-5)
+    assert np.array_equal(np.concatenate(ys), g["y"])
