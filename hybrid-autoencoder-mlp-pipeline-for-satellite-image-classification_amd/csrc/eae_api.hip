@@ -1,0 +1,547 @@
+// C ABI of libeae.so (include/eae.h): context, arena layout, the fused forward / backward / Adam step of the
+// supervised autoencoder, and thin per-op wrappers used by the kernel-level parity tests.
+#include "eae_internal.h"
+#include "eae_conv.cuh"
+#include "eae_edge.cuh"
+#include "eae_wgrad.cuh"
+#include "eae_fc.cuh"
+#include <string>
+#include <vector>
+#include <cmath>
+#include <cstring>
+
+static thread_local std::string g_err;
+int eae_set_error(int code, const char* msg) { g_err = msg ? msg : "unknown error"; return code; }
+extern "C" const char* eae_last_error(void) { return g_err.c_str(); }
+extern "C" int eae_version(void) { return 100; }
+
+namespace {
+
+constexpr float BN_EPS = 1e-5f, BN_MOM = 0.1f;
+const int ENC_C[5] = {3, 32, 64, 128, 256};
+const int BN_C[7] = {32, 64, 128, 256, 128, 64, 32};
+const int BN_GAMMA_IDX[7] = {2, 6, 10, 14, 22, 26, 30};
+const int W3_PARAM[6] = {4, 8, 12, 20, 24, 28};      // conv2, conv3, conv4, deconv1, deconv2, deconv3
+const int W3_A[6] = {64, 128, 256, 256, 128, 64};
+const int W3_B[6] = {32, 64, 128, 128, 64, 32};
+const int PREBN_BIAS[7] = {1, 5, 9, 13, 21, 25, 29};  // biases in front of a BatchNorm: gradient is identically zero
+
+long long r4(long long n) { return (n + 3) & ~3LL; }
+
+void param_sizes(const eae_config& c, long long* sz) {
+  const long long P = (long long)(c.image_h / 16) * (c.image_w / 16), K = 256 * P, L = c.latent_dim, C = c.num_classes;
+  const long long s[38] = {32 * 27, 32, 32, 32, 64 * 32 * 9, 64, 64, 64, 128 * 64 * 9, 128, 128, 128, 256 * 128 * 9, 256, 256, 256,
+                           L * K, L, K * L, K, 256 * 128 * 9, 128, 128, 128, 128 * 64 * 9, 64, 64, 64, 64 * 32 * 9, 32, 32, 32,
+                           32 * 27, 3, 128 * L, 128, C * 128, C};
+  for (int i = 0; i < 38; ++i) sz[i] = s[i];
+}
+
+int check_cfg(const eae_config* c) {
+  if (!c) return eae_set_error(EAE_ERR_ARG, "config is NULL");
+  if (c->image_h <= 0 || c->image_w <= 0 || c->image_h % 64 || c->image_w % 64) return eae_set_error(EAE_ERR_ARG, "image size must be a positive multiple of 64");
+  if (c->latent_dim <= 0 || c->latent_dim % 64) return eae_set_error(EAE_ERR_ARG, "latent_dim must be a positive multiple of 64");
+  if (c->num_classes <= 0 || c->num_classes > 16) return eae_set_error(EAE_ERR_ARG, "num_classes must be in 1..16");
+  if (c->max_batch <= 0) return eae_set_error(EAE_ERR_ARG, "max_batch must be positive");
+  return 0;
+}
+
+}  // namespace
+
+struct eae_ctx {
+  eae_config cfg;
+  int H, W, L, C, Bm;
+  long long Pn, K;                 // pixels of the 256-channel map, flattened features
+  long long poff[39], bnoff[15];
+  float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *bnrun = nullptr;
+  long long* nbt = nullptr;
+  long long adam_step = 0;
+  bool packed = false;
+  bool fwd_ready = false;          // a train-mode forward with gradient staging is resident in the workspace
+  int fwd_B = 0, fwd_head = 0;
+  const float* fwd_x = nullptr;
+  // workspace
+  void* ws = nullptr;
+  bf16_t *y[4], *u[3], *d0, *gy[4], *gu[3], *gd0, *g4;
+  float *z, *dz, *dzc, *coef_f[7], *coef_b[7], *stat, *wscratch, *fcpart, *msepart, *cepart, *headpart, *lossbuf;
+  long long wscratch_floats, head_stride;
+  uint8_t* pack = nullptr;
+  PackDesc* descs_dev = nullptr;
+  int ndesc = 0;
+  size_t pk_c1, pk_p1[6], pk_p2[6], pk_d4j, pk_d4k, pk_we1, pk_we2, pk_wd1, pk_wd2, pk_bd;
+  long long act_elems(int lvl) const {   // per-image elements of the map after `lvl` stride-2 stages (1..4)
+    return (long long)(H >> lvl) * (W >> lvl) * ENC_C[lvl];
+  }
+};
+
+extern "C" int eae_ae_layout(const eae_config* cfg, long long* param_off, long long* bn_off) {
+  if (int rc = check_cfg(cfg)) return rc;
+  long long sz[38];
+  param_sizes(*cfg, sz);
+  long long o = 0;
+  for (int i = 0; i < 38; ++i) { if (param_off) param_off[i] = o; o += r4(sz[i]); }
+  if (param_off) param_off[38] = o;
+  o = 0;
+  for (int l = 0; l < 7; ++l) {
+    if (bn_off) { bn_off[2 * l] = o; bn_off[2 * l + 1] = o + BN_C[l]; }
+    o += 2 * BN_C[l];
+  }
+  if (bn_off) bn_off[14] = o;
+  return 0;
+}
+
+extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
+  if (!out) return eae_set_error(EAE_ERR_ARG, "out is NULL");
+  if (int rc = check_cfg(cfg)) return rc;
+  eae_ctx* c = new eae_ctx();
+  c->cfg = *cfg; c->H = cfg->image_h; c->W = cfg->image_w; c->L = cfg->latent_dim; c->C = cfg->num_classes; c->Bm = cfg->max_batch;
+  c->Pn = (long long)(c->H / 16) * (c->W / 16); c->K = 256 * c->Pn;
+  eae_ae_layout(cfg, c->poff, c->bnoff);
+  const long long Bm = c->Bm;
+  // ---- carve one allocation
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  size_t o_y[4], o_u[3], o_gy[4], o_gu[3];
+  for (int i = 0; i < 4; ++i) { o_y[i] = carve(Bm * c->act_elems(i + 1) * 2); o_gy[i] = carve(Bm * c->act_elems(i + 1) * 2); }
+  for (int i = 0; i < 3; ++i) { o_u[i] = carve(Bm * c->act_elems(3 - i) * 2); o_gu[i] = carve(Bm * c->act_elems(3 - i) * 2); }
+  size_t o_d0 = carve(Bm * c->K * 2), o_gd0 = carve(Bm * c->K * 2), o_g4 = carve(Bm * (size_t)c->H * c->W * 4 * 2);
+  size_t o_z = carve(Bm * c->L * 4), o_dz = carve(Bm * c->L * 4), o_dzc = carve(Bm * c->L * 4);
+  size_t o_cf[7], o_cb[7];
+  for (int l = 0; l < 7; ++l) { o_cf[l] = carve(4 * BN_C[l] * 4); o_cb[l] = carve(3 * BN_C[l] * 4); }
+  // statistics partials: the largest producer is conv1 / deconv4-backward (tiles x 2 x 32) or enc.fc backward (mtiles*P x 2 x 256)
+  long long stat_floats = 0;
+  {
+    long long t1 = (long long)eae_edge_tiles((int)Bm, c->H, c->W) * 2 * 32;
+    long long t2 = (long long)eae_conv_s2_ntiles(0, (int)Bm, c->H / 2, c->W / 2) * 2 * 64;
+    long long t3 = ((Bm + 127) / 128) * c->Pn * 2 * 256;
+    long long t4 = (long long)eae_conv_s2_ntiles(1, (int)Bm, c->H / 4, c->W / 4) * 2 * 32;
+    long long t5 = (long long)eae_conv_s2_ntiles(1, (int)Bm, c->H / 8, c->W / 8) * 2 * 64 + (long long)Bm * 2 * 256;
+    stat_floats = std::max(std::max(t1, t2), std::max(t3, std::max(t4, t5))) + 1024;
+  }
+  size_t o_stat = carve(stat_floats * 4);
+  c->wscratch_floats = 6LL * 1024 * 1024;    // 24 MB of fp32 split-K partials
+  size_t o_wscr = carve(c->wscratch_floats * 4);
+  const int ksplit = (int)(c->K / 128);
+  size_t o_fcp = carve((size_t)ksplit * Bm * c->L * 4);
+  size_t o_mse = carve((size_t)eae_edge_tiles((int)Bm, c->H, c->W) * 4 * 4);
+  const long long hb = (Bm + 31) / 32;
+  c->head_stride = r4(128LL * c->L) + 128 + r4(128LL * c->C) + r4(c->C);
+  size_t o_ce = carve(hb * 2 * 4), o_head = carve(hb * c->head_stride * 4), o_loss = carve(64 * 4);
+  // ---- pack arena
+  size_t poffb = 0;
+  auto pcarve = [&](size_t bytes) { size_t o = poffb; poffb += (bytes + 255) & ~(size_t)255; return o; };
+  std::vector<PackDesc> descs;
+  auto add = [&](long long src, size_t dst, long long cnt, int mode, int d0, int d1, int d2, int f32) {
+    PackDesc d; d.src_off = src; d.dst_off = (long long)dst; d.count = cnt; d.mode = mode; d.d0 = d0; d.d1 = d1; d.d2 = d2; d.out_f32 = f32;
+    descs.push_back(d);
+  };
+  c->pk_c1 = pcarve(32 * 32 * 2); add(c->poff[0], c->pk_c1, 32 * 32, PACK_K27, 32, 3, 0, 0);
+  for (int i = 0; i < 6; ++i) {
+    long long n = (long long)W3_A[i] * W3_B[i] * 9;
+    c->pk_p1[i] = pcarve(n * 2); add(c->poff[W3_PARAM[i]], c->pk_p1[i], n, PACK_3x3_P1, W3_A[i], W3_B[i], 0, 0);
+    c->pk_p2[i] = pcarve(n * 2); add(c->poff[W3_PARAM[i]], c->pk_p2[i], n, PACK_3x3_P2, W3_A[i], W3_B[i], 0, 0);
+  }
+  c->pk_d4j = pcarve(16 * 128 * 2); add(c->poff[32], c->pk_d4j, 16 * 128, PACK_DECONV4_JOINT, 0, 0, 0, 0);
+  c->pk_d4k = pcarve(32 * 32 * 2); add(c->poff[32], c->pk_d4k, 32 * 32, PACK_K27, 32, 3, 0, 0);
+  const long long LK = c->L * c->K;
+  c->pk_we1 = pcarve(LK * 2); add(c->poff[16], c->pk_we1, LK, PACK_FC_ROWMAJOR_KPERM, c->L, 256, (int)c->Pn, 0);
+  c->pk_we2 = pcarve(LK * 2); add(c->poff[16], c->pk_we2, LK, PACK_FC_TRANS_KPERM, c->L, 256, (int)c->Pn, 0);
+  c->pk_wd1 = pcarve(LK * 2); add(c->poff[18], c->pk_wd1, LK, PACK_FC_ROWPERM, c->L, 256, (int)c->Pn, 0);
+  c->pk_wd2 = pcarve(LK * 2); add(c->poff[18], c->pk_wd2, LK, PACK_FC_ROWPERM_TRANS, c->L, 256, (int)c->Pn, 0);
+  c->pk_bd = pcarve(c->K * 4); add(c->poff[19], c->pk_bd, c->K, PACK_FC_ROWPERM, 1, 256, (int)c->Pn, 1);
+  c->ndesc = (int)descs.size();
+  size_t o_pack = carve(poffb), o_desc = carve(descs.size() * sizeof(PackDesc));
+  hipError_t e = hipMalloc(&c->ws, off);
+  if (e != hipSuccess) { delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
+  uint8_t* b = static_cast<uint8_t*>(c->ws);
+  for (int i = 0; i < 4; ++i) { c->y[i] = (bf16_t*)(b + o_y[i]); c->gy[i] = (bf16_t*)(b + o_gy[i]); }
+  for (int i = 0; i < 3; ++i) { c->u[i] = (bf16_t*)(b + o_u[i]); c->gu[i] = (bf16_t*)(b + o_gu[i]); }
+  c->d0 = (bf16_t*)(b + o_d0); c->gd0 = (bf16_t*)(b + o_gd0); c->g4 = (bf16_t*)(b + o_g4);
+  c->z = (float*)(b + o_z); c->dz = (float*)(b + o_dz); c->dzc = (float*)(b + o_dzc);
+  for (int l = 0; l < 7; ++l) { c->coef_f[l] = (float*)(b + o_cf[l]); c->coef_b[l] = (float*)(b + o_cb[l]); }
+  c->stat = (float*)(b + o_stat); c->wscratch = (float*)(b + o_wscr); c->fcpart = (float*)(b + o_fcp);
+  c->msepart = (float*)(b + o_mse); c->cepart = (float*)(b + o_ce); c->headpart = (float*)(b + o_head); c->lossbuf = (float*)(b + o_loss);
+  c->pack = b + o_pack; c->descs_dev = (PackDesc*)(b + o_desc);
+  e = hipMemcpy(c->descs_dev, descs.data(), descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(c->g4, 0, Bm * (size_t)c->H * c->W * 4 * 2);
+  if (e != hipSuccess) { hipFree(c->ws); delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
+  *out = c;
+  return 0;
+}
+
+extern "C" int eae_destroy(eae_ctx* c) {
+  if (!c) return 0;
+  hipDeviceSynchronize();
+  if (c->ws) hipFree(c->ws);
+  delete c;
+  return 0;
+}
+
+extern "C" int eae_bind(eae_ctx* c, float* params, float* grads, float* adam_m, float* adam_v, float* bn_running, long long* bn_nbt) {
+  if (!c || !params || !bn_running) return eae_set_error(EAE_ERR_ARG, "bind: ctx, params and bn_running are required");
+  c->P = params; c->G = grads; c->M = adam_m; c->V = adam_v; c->bnrun = bn_running; c->nbt = bn_nbt;
+  c->packed = false; c->fwd_ready = false;
+  return 0;
+}
+extern "C" int eae_params_changed(eae_ctx* c) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->packed = false; c->fwd_ready = false; return 0; }
+extern "C" int eae_set_adam_step(eae_ctx* c, long long s) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->adam_step = s; return 0; }
+extern "C" long long eae_get_adam_step(eae_ctx* c) { return c ? c->adam_step : -1; }
+
+namespace {
+
+#define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+int ensure_packed(eae_ctx* c, hipStream_t st) {
+  if (c->packed) return 0;
+  RC(eae_launch_pack_all(st, c->descs_dev, c->ndesc, c->P, c->pack));
+  c->packed = true;
+  return 0;
+}
+
+SrcDesc src_raw(const bf16_t* p) { SrcDesc s; s.p0 = p; s.p1 = nullptr; s.coef = nullptr; return s; }
+SrcDesc src_bnrelu(const bf16_t* y, const float* coef) { SrcDesc s; s.p0 = y; s.p1 = nullptr; s.coef = coef; return s; }
+SrcDesc src_bnbwd(const bf16_t* g, const bf16_t* y, const float* coef) { SrcDesc s; s.p0 = g; s.p1 = y; s.coef = coef; return s; }
+SrcDesc src_f32(const float* p) { SrcDesc s; s.p0 = reinterpret_cast<const bf16_t*>(p); s.p1 = nullptr; s.coef = nullptr; return s; }
+
+int bn_fwd_finalize(eae_ctx* c, hipStream_t st, int l, int ntiles, long long count, bool train) {
+  const float* gamma = c->P + c->poff[BN_GAMMA_IDX[l]];
+  const float* beta = c->P + c->poff[BN_GAMMA_IDX[l] + 1];
+  float* rm = c->bnrun + c->bnoff[2 * l];
+  float* rv = c->bnrun + c->bnoff[2 * l + 1];
+  if (train) return eae_launch_bn_finalize(st, c->stat, ntiles, BN_C[l], count, gamma, beta, rm, rv, c->nbt ? c->nbt + l : nullptr, BN_MOM, BN_EPS, c->coef_f[l]);
+  return eae_launch_bn_eval_coef(st, BN_C[l], gamma, beta, rm, rv, BN_EPS, c->coef_f[l]);
+}
+
+int bn_bwd_fin(eae_ctx* c, hipStream_t st, int l, int ntiles, long long count) {
+  return eae_launch_bn_bwd_finalize(st, c->stat, ntiles, BN_C[l], count, c->P + c->poff[BN_GAMMA_IDX[l]], c->coef_f[l],
+                                    c->G + c->poff[BN_GAMMA_IDX[l]], c->G + c->poff[BN_GAMMA_IDX[l] + 1], c->coef_b[l]);
+}
+
+// ---- encoder: x -> y[0..3] (raw, bf16) + BN coefficients -> z (fp32)
+int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
+  const int H = c->H, W = c->W;
+  {
+    EdgeArgs a;
+    a.src3 = x; a.B = B; a.H = H; a.W = W;
+    a.c = ConvArgs();
+    a.c.wpack = (const bf16_t*)(c->pack + c->pk_c1); a.c.bias = c->P + c->poff[1]; a.c.out = c->y[0];
+    a.c.stat_part = train ? c->stat : nullptr; a.c.B = B;
+    RC(eae_launch_edge_conv(st, SRC3_NCHW_F32, EPI_FWD, a));
+    RC(bn_fwd_finalize(c, st, 0, eae_edge_tiles(B, H, W), (long long)B * (H / 2) * (W / 2), train));
+  }
+  for (int i = 1; i < 4; ++i) {
+    ConvArgs a = ConvArgs();
+    a.src = src_bnrelu(c->y[i - 1], c->coef_f[i - 1]);
+    a.wpack = (const bf16_t*)(c->pack + c->pk_p1[i - 1]); a.bias = c->P + c->poff[4 * i + 1]; a.out = c->y[i];
+    a.stat_part = train ? c->stat : nullptr;
+    a.B = B; a.Hin = H >> i; a.Win = W >> i;
+    RC(eae_launch_conv_s2(a, ENC_C[i], ENC_C[i + 1], SRC_BNRELU, EPI_FWD, st));
+    RC(bn_fwd_finalize(c, st, i, eae_conv_s2_ntiles(0, B, a.Hin, a.Win), (long long)B * (a.Hin / 2) * (a.Win / 2), train));
+  }
+  FcNtArgs f = FcNtArgs();
+  f.a = src_bnrelu(c->y[3], c->coef_f[3]);
+  f.w = (const bf16_t*)(c->pack + c->pk_we1);
+  f.M = B; f.N = c->L; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
+  const int ksplit = (int)(c->K / 128);
+  RC(eae_launch_fc_nt(st, f, SRC_BNRELU, FCE_PARTIAL, ksplit));
+  RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, c->P + c->poff[17], nullptr, c->z));
+  return 0;
+}
+
+// ---- decoder: z (fp32 [B][L]) -> d0, u[0..2] -> deconv4 + sigmoid (+ MSE and its gradient)
+int run_decoder(eae_ctx* c, hipStream_t st, const float* z, int B, bool train, const float* target, float gscale, float* x_hat,
+                bool want_grad, bool want_loss) {
+  const int H = c->H, W = c->W;
+  {
+    FcNtArgs f = FcNtArgs();
+    f.a = src_f32(z);
+    f.w = (const bf16_t*)(c->pack + c->pk_wd1);
+    f.M = B; f.N = (int)c->K; f.K = c->L; f.klen = c->L;
+    f.c = ConvArgs();
+    f.c.out = c->d0; f.c.bias = (const float*)(c->pack + c->pk_bd);
+    RC(eae_launch_fc_nt(st, f, SRC_F32, FCE_BIAS_BF16, 1));
+  }
+  const int cin[3] = {256, 128, 64};
+  for (int i = 0; i < 3; ++i) {
+    ConvArgs a = ConvArgs();
+    a.src = (i == 0) ? src_raw(c->d0) : src_bnrelu(c->u[i - 1], c->coef_f[3 + i]);
+    a.wpack = (const bf16_t*)(c->pack + c->pk_p2[3 + i]); a.bias = c->P + c->poff[21 + 4 * i]; a.out = c->u[i];
+    a.stat_part = train ? c->stat : nullptr;
+    a.B = B; a.Hin = H >> (4 - i); a.Win = W >> (4 - i);
+    RC(eae_launch_deconv_s2(a, cin[i], cin[i] / 2, i == 0 ? SRC_RAW : SRC_BNRELU, EPI_FWD, st));
+    RC(bn_fwd_finalize(c, st, 4 + i, eae_conv_s2_ntiles(1, B, a.Hin, a.Win), (long long)B * (a.Hin * 2) * (a.Win * 2), train));
+  }
+  Deconv4Args d = Deconv4Args();
+  d.src = src_bnrelu(c->u[2], c->coef_f[6]);
+  d.wjoint = (const bf16_t*)(c->pack + c->pk_d4j); d.bias = c->P + c->poff[33];
+  d.x = target; d.x_hat = x_hat; d.g4 = want_grad ? c->g4 : nullptr; d.loss_part = (want_loss || want_grad) ? c->msepart : nullptr;
+  d.gscale = gscale; d.B = B; d.Hin = H / 2; d.Win = W / 2;
+  RC(eae_launch_deconv4_loss(st, SRC_BNRELU, d));
+  return 0;
+}
+
+int run_head(eae_ctx* c, hipStream_t st, int B, const long long* labels, float* logits, bool want_grad) {
+  HeadArgs h = HeadArgs();
+  h.z = c->z; h.w1 = c->P + c->poff[34]; h.b1 = c->P + c->poff[35]; h.w2 = c->P + c->poff[36]; h.b2 = c->P + c->poff[37];
+  h.labels = labels; h.B = B; h.L = c->L; h.C = c->C; h.inv_batch = 1.0f / (float)B;
+  h.logits = logits; h.dz = c->dzc; h.grad_part = want_grad ? c->headpart : nullptr; h.grad_stride = c->head_stride;
+  h.loss_part = c->cepart;
+  return eae_launch_head(st, h);
+}
+
+int check_io(eae_ctx* c, const eae_step_io* io, bool need_grad) {
+  if (!c || !io) return eae_set_error(EAE_ERR_ARG, "ctx / io is NULL");
+  if (!c->P || !c->bnrun) return eae_set_error(EAE_ERR_STATE, "eae_bind has not been called");
+  if (!io->x) return eae_set_error(EAE_ERR_ARG, "io->x is NULL");
+  if (io->B <= 0 || io->B > c->Bm) return eae_set_error(EAE_ERR_ARG, "batch size outside 1..max_batch");
+  if (need_grad) {
+    if (!c->G) return eae_set_error(EAE_ERR_STATE, "no gradient arena bound");
+    if (io->head && !io->labels) return eae_set_error(EAE_ERR_ARG, "labels required when head=1");
+    if (!io->train) return eae_set_error(EAE_ERR_ARG, "gradient step requires train=1 (BatchNorm batch statistics)");
+  }
+  return 0;
+}
+
+int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_grad) {
+  const int B = io->B;
+  const bool train = io->train != 0;
+  RC(ensure_packed(c, st));
+  RC(run_encoder(c, st, io->x, B, train));
+  const double numel = (double)B * 3.0 * c->H * c->W;
+  const float gscale = (float)(2.0 * io->alpha / numel);
+  const bool want_loss = io->loss_accum || io->loss_last;
+  RC(run_decoder(c, st, c->z, B, train, (want_loss || want_grad) ? io->x : nullptr, gscale, io->x_hat, want_grad, want_loss));
+  const bool head = io->head != 0;
+  if (head) RC(run_head(c, st, B, io->labels, io->logits, want_grad));
+  if (io->z) EAE_HIP(hipMemcpyAsync(io->z, c->z, (size_t)B * c->L * 4, hipMemcpyDeviceToDevice, st));
+  if (want_loss || want_grad) {
+    const int n_ce = (head && io->labels) ? (B + 31) / 32 : 0;
+    RC(eae_launch_loss_finalize(st, c->msepart, eae_edge_tiles(B, c->H, c->W), c->cepart, n_ce, io->alpha, numel, B,
+                                want_grad ? c->G + c->poff[33] : nullptr, io->loss_accum, io->loss_last));
+  }
+  return 0;
+}
+
+int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io) {
+  const int B = io->B, H = c->H, W = c->W;
+  const bool head = io->head != 0;
+  // ---- classifier weight gradients (partials written by the head kernel)
+  if (head) {
+    const int nb = (B + 31) / 32;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((c->head_stride / 4 + 63) / 64)), dim3(256), 0, st, c->headpart, nb,
+                       (long)(c->head_stride / 4), c->G + c->poff[34], 1.0f);
+    EAE_LAUNCH_CHECK();
+  } else {
+    EAE_HIP(hipMemsetAsync(c->G + c->poff[34], 0, (size_t)(c->poff[38] - c->poff[34]) * 4, st));
+  }
+  // ---- deconv4: weight gradient, then backward-data into u[2]'s BN+ReLU
+  RC(eae_launch_edge_wgrad(st, SRC3_NHWC4_BF16, c->g4, B, H, W, src_bnrelu(c->u[2], c->coef_f[6]), SRC_BNRELU, c->wscratch,
+                           c->wscratch_floats, c->G + c->poff[32]));
+  {
+    EdgeArgs a;
+    a.src3 = c->g4; a.B = B; a.H = H; a.W = W;
+    a.c = ConvArgs();
+    a.c.wpack = (const bf16_t*)(c->pack + c->pk_d4k); a.c.out = c->gu[2]; a.c.stat_part = c->stat;
+    a.c.yprev = c->u[2]; a.c.prev_coef = c->coef_f[6]; a.c.B = B;
+    RC(eae_launch_edge_conv(st, SRC3_NHWC4_BF16, EPI_MASK, a));
+    RC(bn_bwd_fin(c, st, 6, eae_edge_tiles(B, H, W), (long long)B * (H / 2) * (W / 2)));
+  }
+  // ---- deconv3, deconv2, deconv1 (i = 2, 1, 0)
+  const int dcin[3] = {256, 128, 64};
+  for (int i = 2; i >= 0; --i) {
+    const int cs = dcin[i], cb = dcin[i] / 2;         // deconv weight [cs][cb][3][3]
+    const int Hs = H >> (4 - i), Ws = W >> (4 - i);   // input (small) map of the deconv
+    WgradArgs w = WgradArgs();
+    w.small = (i == 0) ? src_raw(c->d0) : src_bnrelu(c->u[i - 1], c->coef_f[3 + i]);
+    w.big = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
+    w.B = B; w.Hs = Hs; w.Ws = Ws;
+    RC(eae_launch_wgrad_s2(st, w, cs, cb, i == 0 ? SRC_RAW : SRC_BNRELU, SRC_BNBWD, c->wscratch, c->wscratch_floats,
+                           c->G + c->poff[20 + 4 * i]));
+    ConvArgs a = ConvArgs();
+    a.src = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
+    a.wpack = (const bf16_t*)(c->pack + c->pk_p1[3 + i]);
+    a.B = B; a.Hin = Hs * 2; a.Win = Ws * 2;
+    if (i > 0) {
+      a.out = c->gu[i - 1]; a.stat_part = c->stat; a.yprev = c->u[i - 1]; a.prev_coef = c->coef_f[3 + i];
+      RC(eae_launch_conv_s2(a, cb, cs, SRC_BNBWD, EPI_MASK, st));
+      RC(bn_bwd_fin(c, st, 3 + i, eae_conv_s2_ntiles(0, B, a.Hin, a.Win), (long long)B * Hs * Ws));
+    } else {
+      a.out = c->gd0;
+      RC(eae_launch_conv_s2(a, cb, cs, SRC_BNBWD, EPI_PLAIN, st));
+    }
+  }
+  // ---- dec.fc: weight/bias gradient and dz
+  {
+    FcTnArgs t = FcTnArgs();
+    t.p = src_raw(c->gd0); t.q = src_f32(c->z); t.Bt = B; t.I = (int)c->K; t.J = c->L;
+    t.out = c->G + c->poff[18]; t.colsum = c->G + c->poff[19]; t.out_mode = 0; t.Pn = (int)c->Pn;
+    RC(eae_launch_fc_tn(st, t, SRC_RAW, SRC_F32));
+    FcNtArgs f = FcNtArgs();
+    f.a = src_raw(c->gd0); f.w = (const bf16_t*)(c->pack + c->pk_wd2);
+    f.M = B; f.N = c->L; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
+    const int ksplit = (int)(c->K / 128);
+    RC(eae_launch_fc_nt(st, f, SRC_RAW, FCE_PARTIAL, ksplit));
+    RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, nullptr, head ? c->dzc : nullptr, c->dz));
+  }
+  // ---- enc.fc: weight/bias gradient and backward-data into y[3]'s BN+ReLU
+  {
+    FcTnArgs t = FcTnArgs();
+    t.p = src_f32(c->dz); t.q = src_bnrelu(c->y[3], c->coef_f[3]); t.Bt = B; t.I = c->L; t.J = (int)c->K;
+    t.out = c->G + c->poff[16]; t.colsum = c->G + c->poff[17]; t.out_mode = 1; t.Pn = (int)c->Pn;
+    RC(eae_launch_fc_tn(st, t, SRC_F32, SRC_BNRELU));
+    FcNtArgs f = FcNtArgs();
+    f.a = src_f32(c->dz); f.w = (const bf16_t*)(c->pack + c->pk_we2);
+    f.M = B; f.N = (int)c->K; f.K = c->L; f.klen = c->L;
+    f.c = ConvArgs();
+    f.c.out = c->gy[3]; f.c.stat_part = c->stat; f.c.yprev = c->y[3]; f.c.prev_coef = c->coef_f[3];
+    RC(eae_launch_fc_nt(st, f, SRC_F32, FCE_MASK, 1));
+    RC(bn_bwd_fin(c, st, 3, ((B + 127) / 128) * (int)c->Pn, (long long)B * c->Pn));
+  }
+  // ---- conv4, conv3, conv2 (i = 3, 2, 1): weight gradient + backward-data
+  for (int i = 3; i >= 1; --i) {
+    const int cs = ENC_C[i + 1], cb = ENC_C[i];       // conv weight [cs][cb][3][3]
+    const int Hs = H >> (i + 1), Ws = W >> (i + 1);   // output (small) map of the conv
+    WgradArgs w = WgradArgs();
+    w.small = src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
+    w.big = src_bnrelu(c->y[i - 1], c->coef_f[i - 1]);
+    w.B = B; w.Hs = Hs; w.Ws = Ws;
+    RC(eae_launch_wgrad_s2(st, w, cs, cb, SRC_BNBWD, SRC_BNRELU, c->wscratch, c->wscratch_floats, c->G + c->poff[4 * i]));
+    ConvArgs a = ConvArgs();
+    a.src = src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
+    a.wpack = (const bf16_t*)(c->pack + c->pk_p2[i - 1]);
+    a.out = c->gy[i - 1]; a.stat_part = c->stat; a.yprev = c->y[i - 1]; a.prev_coef = c->coef_f[i - 1];
+    a.B = B; a.Hin = Hs; a.Win = Ws;
+    RC(eae_launch_deconv_s2(a, cs, cb, SRC_BNBWD, EPI_MASK, st));
+    RC(bn_bwd_fin(c, st, i - 1, eae_conv_s2_ntiles(1, B, Hs, Ws), (long long)B * (Hs * 2) * (Ws * 2)));
+  }
+  // ---- conv1 weight gradient
+  RC(eae_launch_edge_wgrad(st, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, c->wscratch,
+                           c->wscratch_floats, c->G + c->poff[0]));
+  // ---- biases in front of a BatchNorm: gradient is identically zero (the reference computes ~1e-9 rounding noise)
+  for (int k = 0; k < 7; ++k)
+    EAE_HIP(hipMemsetAsync(c->G + c->poff[PREBN_BIAS[k]], 0, (size_t)(c->poff[PREBN_BIAS[k] + 1] - c->poff[PREBN_BIAS[k]]) * 4, st));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int eae_ae_forward(eae_ctx* c, void* stream, const eae_step_io* io) {
+  RC(check_io(c, io, false));
+  c->fwd_ready = false;
+  return forward_impl(c, (hipStream_t)stream, io, false);
+}
+
+extern "C" int eae_ae_grad_step(eae_ctx* c, void* stream, const eae_step_io* io) {
+  RC(check_io(c, io, true));
+  hipStream_t st = (hipStream_t)stream;
+  RC(forward_impl(c, st, io, true));
+  return backward_impl(c, st, io);
+}
+
+extern "C" int eae_adam_step(eae_ctx* c, void* stream, float lr, float weight_decay) {
+  if (!c || !c->P || !c->G || !c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: parameter, gradient and moment arenas must be bound");
+  c->adam_step += 1;
+  RC(eae_launch_adam((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step));
+  c->packed = false;
+  return 0;
+}
+
+extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io, float lr) {
+  RC(eae_ae_grad_step(c, stream, io));
+  return eae_adam_step(c, stream, lr, 0.0f);
+}
+
+extern "C" int eae_encoder_forward(eae_ctx* c, void* stream, const float* x, int B, int train, float* z) {
+  if (!c || !x || !z) return eae_set_error(EAE_ERR_ARG, "encoder_forward: NULL argument");
+  if (!c->P || !c->bnrun) return eae_set_error(EAE_ERR_STATE, "eae_bind has not been called");
+  if (B <= 0 || B > c->Bm) return eae_set_error(EAE_ERR_ARG, "batch size outside 1..max_batch");
+  hipStream_t st = (hipStream_t)stream;
+  c->fwd_ready = false;
+  RC(ensure_packed(c, st));
+  RC(run_encoder(c, st, x, B, train != 0));
+  EAE_HIP(hipMemcpyAsync(z, c->z, (size_t)B * c->L * 4, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+extern "C" int eae_decoder_forward(eae_ctx* c, void* stream, const float* z, int B, int train, float* x_hat) {
+  if (!c || !x_hat || !z) return eae_set_error(EAE_ERR_ARG, "decoder_forward: NULL argument");
+  if (!c->P || !c->bnrun) return eae_set_error(EAE_ERR_STATE, "eae_bind has not been called");
+  if (B <= 0 || B > c->Bm) return eae_set_error(EAE_ERR_ARG, "batch size outside 1..max_batch");
+  hipStream_t st = (hipStream_t)stream;
+  c->fwd_ready = false;
+  RC(ensure_packed(c, st));
+  return run_decoder(c, st, z, B, train != 0, nullptr, 0.f, x_hat, false, false);
+}
+
+// ------------------------------------------------------------------------------------------- per-op wrappers
+namespace {
+SrcDesc to_src(const eae_src& s) {
+  SrcDesc d; d.p0 = (const bf16_t*)s.p0; d.p1 = (const bf16_t*)s.p1; d.coef = s.coef; return d;
+}
+}  // namespace
+
+extern "C" int eae_op_conv_s2(void* stream, int kind, eae_src src, int cin, int cout, int B, int Hin, int Win, const void* wpack,
+                              const float* bias, void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef) {
+  ConvArgs a = ConvArgs();
+  a.src = to_src(src); a.wpack = (const bf16_t*)wpack; a.bias = bias; a.out = (bf16_t*)out; a.stat_part = stat_part;
+  a.yprev = (const bf16_t*)yprev; a.prev_coef = prev_coef; a.B = B; a.Hin = Hin; a.Win = Win;
+  if (kind == 0) return eae_launch_conv_s2(a, cin, cout, src.mode, epilogue, (hipStream_t)stream);
+  return eae_launch_deconv_s2(a, cin, cout, src.mode, epilogue, (hipStream_t)stream);
+}
+extern "C" int eae_op_conv_s2_ntiles(int kind, int B, int Hin, int Win) { return eae_conv_s2_ntiles(kind, B, Hin, Win); }
+
+extern "C" int eae_op_edge_conv(void* stream, int src3_kind, const void* src3, int B, int H, int W, const void* wpack, const float* bias,
+                                void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef) {
+  EdgeArgs a;
+  a.src3 = src3; a.B = B; a.H = H; a.W = W;
+  a.c = ConvArgs();
+  a.c.wpack = (const bf16_t*)wpack; a.c.bias = bias; a.c.out = (bf16_t*)out; a.c.stat_part = stat_part;
+  a.c.yprev = (const bf16_t*)yprev; a.c.prev_coef = prev_coef; a.c.B = B;
+  return eae_launch_edge_conv((hipStream_t)stream, src3_kind, epilogue, a);
+}
+extern "C" int eae_op_edge_wgrad(void* stream, int src3_kind, const void* src3, int B, int H, int W, eae_src side, float* scratch,
+                                 long long scratch_floats, float* dw) {
+  return eae_launch_edge_wgrad((hipStream_t)stream, src3_kind, src3, B, H, W, to_src(side), side.mode, scratch, scratch_floats, dw);
+}
+extern "C" int eae_op_deconv4_loss(void* stream, eae_src a3, int B, int Hin, int Win, const void* wjoint, const float* bias,
+                                   const float* x, float gscale, float* x_hat, void* g4, float* loss_part) {
+  Deconv4Args d = Deconv4Args();
+  d.src = to_src(a3); d.wjoint = (const bf16_t*)wjoint; d.bias = bias; d.x = x; d.x_hat = x_hat; d.g4 = (bf16_t*)g4;
+  d.loss_part = loss_part; d.gscale = gscale; d.B = B; d.Hin = Hin; d.Win = Win;
+  return eae_launch_deconv4_loss((hipStream_t)stream, a3.mode, d);
+}
+extern "C" int eae_op_wgrad_s2(void* stream, eae_src small_src, eae_src big_src, int cs, int cb, int B, int Hs, int Ws, float* scratch,
+                               long long scratch_floats, float* dw) {
+  WgradArgs w = WgradArgs();
+  w.small = to_src(small_src); w.big = to_src(big_src); w.B = B; w.Hs = Hs; w.Ws = Ws;
+  return eae_launch_wgrad_s2((hipStream_t)stream, w, cs, cb, small_src.mode, big_src.mode, scratch, scratch_floats, dw);
+}
+extern "C" int eae_op_bn_finalize(void* stream, const float* stat_part, int ntiles, int C, long long count, const float* gamma,
+                                  const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef) {
+  return eae_launch_bn_finalize((hipStream_t)stream, stat_part, ntiles, C, count, gamma, beta, rm, rv, nbt, momentum, eps, coef);
+}
+extern "C" int eae_op_bn_eval_coef(void* stream, int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                   float eps, float* coef) {
+  return eae_launch_bn_eval_coef((hipStream_t)stream, C, gamma, beta, rm, rv, eps, coef);
+}
+extern "C" int eae_op_bn_bwd_finalize(void* stream, const float* stat_part, int ntiles, int C, long long count, const float* gamma,
+                                      const float* coef_fwd, float* dgamma, float* dbeta, float* coef_bwd) {
+  return eae_launch_bn_bwd_finalize((hipStream_t)stream, stat_part, ntiles, C, count, gamma, coef_fwd, dgamma, dbeta, coef_bwd);
+}
+extern "C" int eae_op_pack3x3(void* stream, const float* w, int A, int B, void* p1, void* p2) {
+  // one-off helper for tests: builds a 2-entry descriptor table on the fly (synchronous upload)
+  PackDesc d[2];
+  long long n = (long long)A * B * 9;
+  d[0] = PackDesc{0, 0, n, PACK_3x3_P1, A, B, 0, 0};
+  d[1] = PackDesc{0, (long long)((char*)p2 - (char*)p1), n, PACK_3x3_P2, A, B, 0, 0};
+  PackDesc* dev = nullptr;
+  EAE_HIP(hipMalloc(&dev, sizeof(d)));
+  EAE_HIP(hipMemcpy(dev, d, sizeof(d), hipMemcpyHostToDevice));
+  int rc = eae_launch_pack_all((hipStream_t)stream, dev, 2, w, p1);
+  hipStreamSynchronize((hipStream_t)stream);
+  hipFree(dev);
+  return rc;
+}
+extern "C" int eae_op_adam(void* stream, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
+                           double eps, double wd, long long step) {
+  return eae_launch_adam((hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, wd, step);
+}

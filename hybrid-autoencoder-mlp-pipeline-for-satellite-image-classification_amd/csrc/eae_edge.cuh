@@ -1,0 +1,351 @@
+// Kernels for the two 3-channel "edge" layers, which carry the most bytes and the least math (hard parts):
+//   enc.conv1  (R.md:292)  x fp32 NCHW [B,3,H,W]            -> y1 [B,H/2,W/2,32]
+//   dec.deconv4 (R.md:382) a3 [B,H/2,W/2,32] -> sigmoid -> x_hat [B,3,H,W], fused with MSE loss and its gradient
+// K = 27 is padded to 32 in LDS only (one v_mfma_f32_16x16x32_bf16 K-step), N = 3 is handled by computing the four
+// sub-pixel phases jointly (N = 4 phases x 3 channels = 12 of 16 MFMA columns), never by padding in HBM.
+#pragma once
+#include "eae_common.cuh"
+#include "eae_conv.cuh"
+
+enum { SRC3_NCHW_F32 = 0,     // fp32 planar image (the loader contract)
+       SRC3_NHWC4_BF16 = 1 }; // bf16 pixels padded to 4 channels (gradient of the pre-sigmoid output)
+
+constexpr int E_TH = 4, E_TW = 32;                 // 128 output pixels (conv view) / 128 input positions (deconv view)
+constexpr int E_PH = 2 * E_TH + 1, E_PW = 2 * E_TW + 1;   // 9 x 65 patch of the 3-channel tensor
+constexpr int E_PATCH = E_PH * E_PW * 4;           // bf16 elements ([row][col][4])
+constexpr int E_AT = 128 * PIX_STRIDE;             // im2col tile [128][32 + pad]
+
+// Stage the 3-channel patch (rows iy0.., cols ix0..) as bf16 [E_PH][E_PW][4] with zero padding outside the image.
+template <int SRC3>
+__device__ __forceinline__ void stage_patch3(const void* src, bf16_t* p3, int n, int H, int W, int iy0, int ix0) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < E_PH * E_PW; i += 256) {     // clear channel 3 and the borders
+    *reinterpret_cast<uint2*>(p3 + i * 4) = make_uint2(0, 0);
+  }
+  __syncthreads();
+  if (SRC3 == SRC3_NCHW_F32) {
+    const float* x = static_cast<const float*>(src);
+    // interior columns ix0+1 .. ix0+64 are image columns (ix0 = 2*tx0-1, tx0 multiple of 32 -> 16-byte aligned rows)
+    for (int i = tid; i < 3 * E_PH * 16; i += 256) {
+      int c4 = i % 16, r = (i / 16) % E_PH, c = i / (16 * E_PH);
+      int iy = iy0 + r, ix = ix0 + 1 + c4 * 4;
+      if (iy < 0 || iy >= H) continue;
+      float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * 3 + c) * H + iy) * W + ix);
+      bf16_t* d = p3 + (r * E_PW + 1 + c4 * 4) * 4 + c;
+      d[0] = (bf16_t)f2bf(v.x); d[4] = (bf16_t)f2bf(v.y); d[8] = (bf16_t)f2bf(v.z); d[12] = (bf16_t)f2bf(v.w);
+    }
+    if (ix0 >= 0)                                        // left halo column is a real pixel for tiles not at the image edge
+      for (int i = tid; i < 3 * E_PH; i += 256) {
+        int r = i % E_PH, c = i / E_PH, iy = iy0 + r;
+        if (iy >= 0 && iy < H) p3[(r * E_PW) * 4 + c] = (bf16_t)f2bf(x[(((size_t)n * 3 + c) * H + iy) * W + ix0]);
+      }
+  } else {
+    const bf16_t* g = static_cast<const bf16_t*>(src);
+    for (int i = tid; i < E_PH * 32; i += 256) {       // 2 pixels (16 B) per piece
+      int c2 = i % 32, r = i / 32;
+      int iy = iy0 + r, ix = ix0 + 1 + c2 * 2;
+      if (iy < 0 || iy >= H) continue;
+      uint4 v = *reinterpret_cast<const uint4*>(g + (((size_t)n * H + iy) * W + ix) * 4);
+      bf16_t* d = p3 + (r * E_PW + 1 + c2 * 2) * 4;
+      *reinterpret_cast<uint2*>(d) = make_uint2(v.x, v.y);
+      *reinterpret_cast<uint2*>(d + 4) = make_uint2(v.z, v.w);
+    }
+    if (ix0 >= 0)
+      for (int r = tid; r < E_PH; r += 256) {
+        int iy = iy0 + r;
+        if (iy >= 0 && iy < H)
+          *reinterpret_cast<uint2*>(p3 + (r * E_PW) * 4) = *reinterpret_cast<const uint2*>(g + (((size_t)n * H + iy) * W + ix0) * 4);
+      }
+  }
+  __syncthreads();
+}
+
+// Build the im2col tile [128 pixels][32 k] (k = tap*3 + c, zero for k >= 27) from the staged patch.
+__device__ __forceinline__ void build_im2col27(const bf16_t* p3, bf16_t* at) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int q = tid + i * 256;
+    int m = q >> 2, kg = q & 3;
+    int ty = m / E_TW, tx = m % E_TW;
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      uint32_t e[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        int k = kg * 8 + j + u;
+        int tap = k / 3, c = k % 3;
+        int ky = tap / 3, kx = tap % 3;
+        e[u] = (k < 27) ? (uint32_t)p3[((2 * ty + ky) * E_PW + 2 * tx + kx) * 4 + c] : 0u;
+      }
+      w[j >> 1] = e[0] | (e[1] << 16);
+    }
+    *reinterpret_cast<uint4*>(at + m * PIX_STRIDE + kg * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// out[m][32] = im2col27(src3)[m][32] . Wp[32][32]^T      (conv1 forward; backward-data of deconv4)
+// ---------------------------------------------------------------------------------------------------------------
+struct EdgeArgs {
+  const void* src3;        // fp32 NCHW [B,3,H,W] or bf16 NHWC4 [B,H,W,4]
+  int B, H, W;             // spatial size of the 3-channel tensor
+  ConvArgs c;              // wpack [32][32], bias, out [B,H/2,W/2,32], stat_part, yprev, prev_coef
+};
+
+template <int SRC3, int EPI>
+__global__ __launch_bounds__(256) void edge_conv_kernel(EdgeArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t p3[E_PATCH];
+  __shared__ __attribute__((aligned(16))) bf16_t at[E_AT];            // im2col tile, later the output tile [128][40]
+  __shared__ __attribute__((aligned(16))) float red[2 * 64 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Hout = a.H >> 1, Wout = a.W >> 1;
+  const int tiles_x = Wout / E_TW, tiles_y = Hout / E_TH;
+  int t = blockIdx.x;
+  const int txb = t % tiles_x; t /= tiles_x;
+  const int tyb = t % tiles_y; t /= tiles_y;
+  const int n = t;
+  stage_patch3<SRC3>(a.src3, p3, n, a.H, a.W, 2 * tyb * E_TH - 1, 2 * txb * E_TW - 1);
+  build_im2col27(p3, at);
+  __syncthreads();
+  const int kgl = lane >> 4;
+  f32x4 acc[2][2];
+  bf16x8 af[2], bfr[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+    af[mi] = *reinterpret_cast<const bf16x8*>(at + ((wave * 2 + mi) * 16 + (lane & 15)) * PIX_STRIDE + kgl * 8);
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+    bfr[ni] = *reinterpret_cast<const bf16x8*>(a.c.wpack + (ni * 16 + (lane & 15)) * 32 + kgl * 8);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16(af[mi], bfr[ni], (f32x4){0.f, 0.f, 0.f, 0.f});
+  __syncthreads();
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    int col = ni * 16 + (lane & 15);
+    float bv = (EPI == EPI_FWD) ? a.c.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = (wave * 2 + mi) * 16 + (lane >> 4) * 4 + r;
+        at[row * 40 + col] = (bf16_t)f2bf(acc[mi][ni][r] + bv);
+      }
+  }
+  __syncthreads();
+  auto rowmap = [=](int row) -> long {
+    int ty = row / E_TW, tx = row % E_TW;
+    return (((long)n * Hout + (tyb * E_TH + ty)) * Wout + (txb * E_TW + tx)) * 32;
+  };
+  tile_epilogue<32, 32, EPI>(a.c, at, red, 0, blockIdx.x, 128, rowmap);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// R[k][c] = sum_m im2col27(src3)[m][k] * T(side)[m][c]     (weight gradient of conv1 and of deconv4)
+// Each block sweeps `tiles_per_block` 128-pixel tiles and writes one fp32 partial in the REFERENCE layout
+// [c][3][3][3] (index c*27 + cx*9 + tap with k = tap*3 + cx), summed later by reduce_slices (deterministic).
+// ---------------------------------------------------------------------------------------------------------------
+struct EdgeWgradArgs {
+  const void* src3;
+  int B, H, W;
+  SrcDesc side;           // [B,H/2,W/2,32] tensor with its load transform
+  float* part;            // [nblocks][32*27]
+  int tiles_per_block, ntiles;
+};
+
+template <int SRC3, int SMODE>
+__global__ __launch_bounds__(256) void edge_wgrad_kernel(EdgeWgradArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t p3[E_PATCH];
+  __shared__ __attribute__((aligned(16))) bf16_t at[E_AT];
+  __shared__ __attribute__((aligned(16))) bf16_t st[E_AT];
+  __shared__ float racc[4][2][2][64 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Hout = a.H >> 1, Wout = a.W >> 1;
+  const int tiles_x = Wout / E_TW, tiles_y = Hout / E_TH;
+  const int kgs = tid & 3;
+  ChanCoef<SMODE> cc;
+  cc.load(a.side.coef, 32, kgs * 8);
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  for (int ti = 0; ti < a.tiles_per_block; ++ti) {
+    int t = blockIdx.x * a.tiles_per_block + ti;
+    if (t >= a.ntiles) break;
+    const int txb = t % tiles_x; t /= tiles_x;
+    const int tyb = t % tiles_y; t /= tiles_y;
+    const int n = t;
+    __syncthreads();
+    // side tile [128][32] with transform
+    RawPiece<SMODE> raw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int m = (tid + i * 256) >> 2;
+      int ty = m / E_TW, tx = m % E_TW;
+      size_t off = ((((size_t)n * Hout + tyb * E_TH + ty) * Wout) + txb * E_TW + tx) * 32 + kgs * 8;
+      load_piece<SMODE>(a.side, off, true, raw[i]);
+    }
+    stage_patch3<SRC3>(a.src3, p3, n, a.H, a.W, 2 * tyb * E_TH - 1, 2 * txb * E_TW - 1);
+    build_im2col27(p3, at);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int m = (tid + i * 256) >> 2;
+      *reinterpret_cast<uint4*>(st + m * PIX_STRIDE + kgs * 8) = transform_piece<SMODE>(raw[i], true, cc);
+    }
+    __syncthreads();
+    // wave w reduces pixels 32w .. 32w+31
+    const int r_lo = wave * 32 + 8 * g + q, r_hi = r_lo + 4;
+    bf16x8 ka[2], sb[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      ka[it] = tr_frag(at + r_lo * PIX_STRIDE + it * 16 + 4 * p, at + r_hi * PIX_STRIDE + it * 16 + 4 * p);
+      sb[it] = tr_frag(st + r_lo * PIX_STRIDE + it * 16 + 4 * p, st + r_hi * PIX_STRIDE + it * 16 + 4 * p);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) acc[it][jt] = mfma16(ka[it], sb[jt], acc[it][jt]);
+  }
+  // cross-wave reduction (fixed order) and store in reference layout
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) racc[wave][it][jt][lane * 4 + r] = acc[it][jt][r];
+  __syncthreads();
+  // 4 (it,jt) tiles x 256 values = 1024 outputs; thread handles 4
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int e = tid + i * 256;
+    int tile = e >> 8, idx = e & 255;
+    int it = tile >> 1, jt = tile & 1;
+    float v = racc[0][it][jt][idx] + racc[1][it][jt][idx] + racc[2][it][jt][idx] + racc[3][it][jt][idx];
+    int l = idx >> 2, r = idx & 3;
+    int k = it * 16 + (l >> 4) * 4 + r;     // D row  = k index (im2col side)
+    int c = jt * 16 + (l & 15);             // D col  = side channel
+    if (k < 27) {
+      int tap = k / 3, cx = k % 3;
+      a.part[(size_t)blockIdx.x * (32 * 27) + c * 27 + cx * 9 + tap] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// deconv4 forward (all four phases jointly) + sigmoid + MSE loss + its gradient      (R.md:382-383, 622, 649)
+//   s[n,oy,ox,co] = b[co] + sum over the 2x2 input neighbourhood ;  x_hat = sigmoid(s)
+//   loss partial  = sum (x_hat - x)^2 ;  g4 = gscale * (x_hat - x) * x_hat * (1 - x_hat)   (gscale = alpha*2/numel)
+// ---------------------------------------------------------------------------------------------------------------
+struct Deconv4Args {
+  SrcDesc src;             // a3 = BNRELU(u3)  [B,Hin,Win,32]
+  const bf16_t* wjoint;    // [16][128]  n = phase*3+co, k = nb*32+ci
+  const float* bias;       // [3]
+  const float* x;          // target fp32 NCHW [B,3,2Hin,2Win] or nullptr (forward only)
+  float* x_hat;            // fp32 NCHW or nullptr
+  bf16_t* g4;              // bf16 NHWC4 [B,2Hin,2Win,4] or nullptr
+  float* loss_part;        // [ntiles][4]: sum diff^2, sum g (co = 0,1,2)   or nullptr
+  float gscale;
+  int B, Hin, Win;
+};
+
+template <int SRC>
+__global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
+  constexpr int PH = E_TH + 1, PW = E_TW + 1, NPIX = PH * PW;       // 5 x 33 input pixels
+  constexpr int NPA = (NPIX * 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) bf16_t patch[NPIX * PIX_STRIDE];
+  __shared__ __attribute__((aligned(16))) float sl[128 * 17];
+  __shared__ __attribute__((aligned(16))) bf16_t gl[8 * 64 * 4];
+  __shared__ float redl[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Hout = a.Hin * 2, Wout = a.Win * 2;
+  const int tiles_x = a.Win / E_TW, tiles_y = a.Hin / E_TH;
+  int t = blockIdx.x;
+  const int txb = t % tiles_x; t /= tiles_x;
+  const int tyb = t % tiles_y; t /= tiles_y;
+  const int n = t;
+  const int iy0 = tyb * E_TH, ix0 = txb * E_TW;
+  const int kgs = tid & 3, kgl = lane >> 4;
+  ChanCoef<SRC> cc;
+  cc.load(a.src.coef, 32, kgs * 8);
+  RawPiece<SRC> raw[NPA];
+  bool val[NPA];
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    int qq = tid + i * 256;
+    int pix = qq >> 2;
+    int pr = pix / PW, pc = pix % PW;
+    int iy = iy0 + pr, ix = ix0 + pc;
+    val[i] = (pix < NPIX) && (iy < a.Hin) && (ix < a.Win);
+    size_t off = (((size_t)n * a.Hin + iy) * a.Win + ix) * 32 + kgs * 8;
+    load_piece<SRC>(a.src, off, val[i], raw[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    int qq = tid + i * 256;
+    if (qq < NPIX * 4)
+      *reinterpret_cast<uint4*>(patch + (qq >> 2) * PIX_STRIDE + kgs * 8) = transform_piece<SRC>(raw[i], val[i], cc);
+  }
+  __syncthreads();
+  f32x4 acc[2];
+  acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    bf16x8 bfr = *reinterpret_cast<const bf16x8*>(a.wjoint + (lane & 15) * 128 + nb * 32 + kgl * 8);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      int pos = (wave * 2 + mi) * 16 + (lane & 15);
+      int ty = pos / E_TW, tx = pos % E_TW;
+      bf16x8 af = *reinterpret_cast<const bf16x8*>(patch + ((ty + (nb >> 1)) * PW + tx + (nb & 1)) * PIX_STRIDE + kgl * 8);
+      acc[mi] = mfma16(af, bfr, acc[mi]);
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sl[((wave * 2 + mi) * 16 + (lane >> 4) * 4 + r) * 17 + (lane & 15)] = acc[mi][r];
+  __syncthreads();
+  // elementwise pass in NCHW order: e -> (co, oy, ox) over the 8 x 64 x 3 output tile
+  float lsum = 0.f, gsum[3] = {0.f, 0.f, 0.f};
+  if (a.g4) *reinterpret_cast<uint4*>(gl + tid * 8) = make_uint4(0, 0, 0, 0);   // clears [8*64*4] bf16 = 4 KB
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    int e = tid + i * 256;
+    int ox = e & 63, oy = (e >> 6) & 7, co = e >> 9;
+    int pos = (oy >> 1) * E_TW + (ox >> 1), ph = (oy & 1) * 2 + (ox & 1);
+    float s = sl[pos * 17 + ph * 3 + co] + a.bias[co];
+    float xh = 1.0f / (1.0f + __expf(-s));
+    size_t gi = (((size_t)n * 3 + co) * Hout + (2 * iy0 + oy)) * Wout + 2 * ix0 + ox;
+    if (a.x_hat) a.x_hat[gi] = xh;
+    if (a.x) {
+      float d = xh - a.x[gi];
+      lsum = fmaf(d, d, lsum);
+      if (a.g4) {
+        uint32_t gb = f2bf(a.gscale * d * xh * (1.0f - xh));
+        gl[(oy * 64 + ox) * 4 + co] = (bf16_t)gb;
+        gsum[i >> 1] += bf2f(gb);
+      }
+    }
+  }
+  if (a.loss_part) {
+    float v[4] = {lsum, gsum[0], gsum[1], gsum[2]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v[k] += __shfl_xor(v[k], o);
+      if (lane == 0) redl[wave][k] = v[k];
+    }
+  }
+  __syncthreads();
+  if (a.loss_part && tid < 4) a.loss_part[(size_t)blockIdx.x * 4 + tid] = redl[0][tid] + redl[1][tid] + redl[2][tid] + redl[3][tid];
+  if (a.g4) {
+    int row = tid >> 5, c2 = tid & 31;     // 8 rows x 32 pieces of 2 pixels
+    uint4 v = *reinterpret_cast<const uint4*>(gl + (row * 64 + c2 * 2) * 4);
+    *reinterpret_cast<uint4*>(a.g4 + (((size_t)n * Hout + 2 * iy0 + row) * Wout + 2 * ix0 + c2 * 2) * 4) = v;
+  }
+}

@@ -1,0 +1,56 @@
+// Host-side dispatch of the 3-channel edge-layer kernels (enc.conv1, dec.deconv4).
+#include "eae_internal.h"
+#include "eae_edge.cuh"
+#include "eae_wgrad.cuh"
+
+static int check_edge_shape(int B, int H, int W) {
+  if (B <= 0 || H % 8 || W % 64) return eae_set_error(-2, "edge layer: image height must be a multiple of 8 and width of 64");
+  return 0;
+}
+
+int eae_launch_edge_conv(hipStream_t st, int src3_kind, int epi, const EdgeArgs& a) {
+  if (int rc = check_edge_shape(a.B, a.H, a.W)) return rc;
+  dim3 grid(a.B * (a.H / 2 / E_TH) * (a.W / 2 / E_TW));
+#define CASE(S, E) if (src3_kind == S && epi == E) { hipLaunchKernelGGL((edge_conv_kernel<S, E>), grid, dim3(256), 0, st, a); EAE_LAUNCH_CHECK(); return 0; }
+  CASE(SRC3_NCHW_F32, EPI_FWD)
+  CASE(SRC3_NHWC4_BF16, EPI_MASK)
+  CASE(SRC3_NHWC4_BF16, EPI_PLAIN)
+  CASE(SRC3_NCHW_F32, EPI_PLAIN)
+#undef CASE
+  return eae_set_error(-2, "edge_conv: combination not instantiated");
+}
+
+int eae_edge_tiles(int B, int H, int W) { return B * (H / 2 / E_TH) * (W / 2 / E_TW); }
+
+// dw [32][3][3][3] = reduce over blocks of the per-block partials. scratch must hold nblocks*864 floats.
+int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B, int H, int W, const SrcDesc& side, int smode,
+                          float* scratch, long long scratch_floats, float* dw) {
+  if (int rc = check_edge_shape(B, H, W)) return rc;
+  EdgeWgradArgs a;
+  a.src3 = src3; a.B = B; a.H = H; a.W = W; a.side = side; a.part = scratch;
+  a.ntiles = eae_edge_tiles(B, H, W);
+  int nblocks = a.ntiles < 512 ? a.ntiles : 512;
+  a.tiles_per_block = (a.ntiles + nblocks - 1) / nblocks;
+  nblocks = (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
+  if ((long long)nblocks * 864 > scratch_floats) return eae_set_error(-2, "edge_wgrad: scratch too small");
+#define CASE(S, M) if (src3_kind == S && smode == M) { hipLaunchKernelGGL((edge_wgrad_kernel<S, M>), dim3(nblocks), dim3(256), 0, st, a); EAE_LAUNCH_CHECK(); goto reduce; }
+  CASE(SRC3_NCHW_F32, SRC_BNBWD)
+  CASE(SRC3_NHWC4_BF16, SRC_BNRELU)
+  CASE(SRC3_NCHW_F32, SRC_RAW)
+#undef CASE
+  return eae_set_error(-2, "edge_wgrad: combination not instantiated");
+reduce:
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3((864 / 4 + 63) / 64), dim3(256), 0, st, scratch, nblocks, (long)(864 / 4), dw, 1.0f);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int eae_launch_deconv4_loss(hipStream_t st, int smode, const Deconv4Args& a) {
+  if (a.B <= 0 || a.Hin % E_TH || a.Win % E_TW) return eae_set_error(-2, "deconv4: input must be a multiple of 4 x 32");
+  dim3 grid(a.B * (a.Hin / E_TH) * (a.Win / E_TW));
+  if (smode == SRC_BNRELU) hipLaunchKernelGGL((deconv4_loss_kernel<SRC_BNRELU>), grid, dim3(256), 0, st, a);
+  else if (smode == SRC_RAW) hipLaunchKernelGGL((deconv4_loss_kernel<SRC_RAW>), grid, dim3(256), 0, st, a);
+  else return eae_set_error(-2, "deconv4: source mode not instantiated");
+  EAE_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,226 @@
+// GEMMs of the two latent projections (enc.fc: nn.Linear(256*h*w, L), R.md:309; dec.fc: nn.Linear(L, 256*h*w), R.md:365).
+// Activations stay NHWC inside the engine, so the flattened feature index is k' = p*256 + c (p = pixel, c = channel)
+// while the reference's nn.Flatten index is c*P + p; the permutation lives in the packed weights (eae_misc.hip).
+//
+//   fc_nt_kernel : C[m][n] = sum_k T(A)[m][k] * Wp[n][k]        (forward projections, backward-data)
+//   fc_tn_kernel : R[i][j] = sum_b T(P)[b][i] * T(Q)[b][j]      (weight gradients; reduction over the batch -> both
+//                                                                operands via the transposing LDS read)
+#pragma once
+#include "eae_common.cuh"
+#include "eae_conv.cuh"
+
+enum { FCE_PARTIAL = 0,    // fp32 partial [kslice][M][N]       (split-K)
+       FCE_BIAS_BF16 = 1,  // bf16(acc + bias[n]) -> [M][N]
+       FCE_MASK = 2 };     // ReLU mask of the BN output at the same position + BN-backward partial sums
+
+struct FcNtArgs {
+  SrcDesc a;               // A [M][K]; SRC_F32: p0 is a float*; BNRELU: channel = k % 256
+  const bf16_t* w;         // [N][K]
+  int M, N, K;
+  int klen;                // K-range per grid.z slice (multiple of 64)
+  float* part;             // FCE_PARTIAL
+  ConvArgs c;              // FCE_BIAS_BF16 / FCE_MASK: out, bias ([N]), stat_part, yprev, prev_coef ([4][256])
+};
+
+constexpr int FC_KC = 64;
+constexpr int FC_LS = FC_KC + 8;   // LDS row stride (bf16)
+
+template <int AMODE>
+__device__ __forceinline__ uint4 fc_load_a(const SrcDesc& s, size_t off, bool valid, const float* coef, int ch0) {
+  if (!valid) return make_uint4(0, 0, 0, 0);
+  if (AMODE == SRC_F32) {
+    const float* f = reinterpret_cast<const float*>(s.p0) + off;
+    float4 lo = *reinterpret_cast<const float4*>(f), hi = *reinterpret_cast<const float4*>(f + 4);
+    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return pack8(v);
+  }
+  uint4 r = *reinterpret_cast<const uint4*>(s.p0 + off);
+  if (AMODE == SRC_BNRELU) {
+    float x[8];
+    unpack8(r, x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = fmaxf(fmaf(coef[ch0 + j], x[j], coef[256 + ch0 + j]), 0.f);
+    r = pack8(x);
+  }
+  return r;
+}
+
+// tile 128 (M) x 64 (N); 4 waves 2x2 (each 64 x 32); K chunks of 64
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t al[128 * FC_LS];      // A chunk; later the output tile [128][72]
+  __shared__ __attribute__((aligned(16))) bf16_t wl[64 * FC_LS];
+  __shared__ __attribute__((aligned(16))) float red[2 * 32 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64, kbeg = blockIdx.z * a.klen;
+  const int kgl = lane >> 4, kg8 = tid & 7;
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = kbeg; k0 < kbeg + a.klen; k0 += FC_KC) {
+    if (k0 != kbeg) __syncthreads();
+    uint4 av[4], wv[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = (tid + i * 256) >> 3;
+      int k = k0 + kg8 * 8;
+      av[i] = fc_load_a<AMODE>(a.a, (size_t)(m0 + row) * a.K + k, (m0 + row) < a.M, a.a.coef, k & 255);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int row = (tid + i * 256) >> 3;
+      wv[i] = *reinterpret_cast<const uint4*>(a.w + (size_t)(n0 + row) * a.K + k0 + kg8 * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(al + ((tid + i * 256) >> 3) * FC_LS + kg8 * 8) = av[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(wl + ((tid + i * 256) >> 3) * FC_LS + kg8 * 8) = wv[i];
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[2];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        af[mi] = *reinterpret_cast<const bf16x8*>(al + ((wm * 4 + mi) * 16 + (lane & 15)) * FC_LS + ks * 32 + kgl * 8);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        bfr[ni] = *reinterpret_cast<const bf16x8*>(wl + (wn * 32 + ni * 16 + (lane & 15)) * FC_LS + ks * 32 + kgl * 8);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16(af[mi], bfr[ni], acc[mi][ni]);
+    }
+  }
+  if (EPI == FCE_PARTIAL) {
+    float* out = a.part + (size_t)blockIdx.z * a.M * a.N;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int row = m0 + (wm * 4 + mi) * 16 + (lane >> 4) * 4 + r;
+          int col = n0 + wn * 32 + ni * 16 + (lane & 15);
+          if (row < a.M) out[(size_t)row * a.N + col] = acc[mi][ni][r];
+        }
+    return;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    int col = wn * 32 + ni * 16 + (lane & 15);
+    float bv = (EPI == FCE_BIAS_BF16) ? a.c.bias[n0 + col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = (wm * 4 + mi) * 16 + (lane >> 4) * 4 + r;
+        al[row * FC_LS + col] = (bf16_t)f2bf(acc[mi][ni][r] + bv);
+      }
+  }
+  __syncthreads();
+  const int M = a.M, N = a.N;
+  const int pcol = n0 & ~255, c0 = n0 & 255;       // pixel base column / channel offset inside the 256-channel pixel
+  auto rowmap = [=](int row) -> long { return (m0 + row) < M ? (long)(m0 + row) * N + pcol : -1; };
+  const int tile_id = blockIdx.x * (N / 256) + (n0 >> 8);
+  if (EPI == FCE_MASK) tile_epilogue<256, 64, EPI_MASK>(a.c, al, red, c0, tile_id, 128, rowmap);
+  else tile_epilogue<256, 64, EPI_PLAIN>(a.c, al, red, c0, tile_id, 128, rowmap);
+}
+
+// z (or dz) = bias + sum over K-slices of the split-K partials (+ optional addend), fp32
+static __global__ __launch_bounds__(256) void fc_splitk_reduce_kernel(const float* __restrict__ part, int nsl, int M, int N,
+                                                                const float* __restrict__ bias, const float* __restrict__ addend,
+                                                                float* __restrict__ out) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)M * N) return;
+  float s = bias ? bias[i % N] : 0.f;
+  for (int k = 0; k < nsl; ++k) s += part[(long)k * M * N + i];
+  if (addend) s += addend[i];
+  out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// R[i][j] = sum_b P[b][i] * Q[b][j]; block = 64 (i) x 64 (j); whole batch reduced in chunks of 64 rows.
+// Also emits colsum_P[i] = sum_b P[b][i] (bias gradient) from the blocks with blockIdx.y == 0.
+// out_mode 0: R is [I][J] row-major, row index permuted   i' = p*256+c  ->  c*Pn + p   (dec.fc weight [4096][L])
+// out_mode 1: R is [I][J] row-major, column index permuted j' = p*256+c ->  c*Pn + p   (enc.fc weight [L][4096])
+// ---------------------------------------------------------------------------------------------------------------
+struct FcTnArgs {
+  SrcDesc p, q;            // P [Bt][I], Q [Bt][J]   (F32: p0 is float*; BNRELU: channel = col % 256)
+  int Bt, I, J;
+  float* out;              // reference-layout weight gradient
+  float* colsum;           // bias gradient (reference order) or nullptr
+  int out_mode, Pn;        // Pn = pixels per image of the flattened map
+};
+
+template <int PMODE, int QMODE>
+__global__ __launch_bounds__(256) void fc_tn_kernel(FcTnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t pl[64 * FC_LS];
+  __shared__ __attribute__((aligned(16))) bf16_t ql[64 * FC_LS];
+  __shared__ float csum[32][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+  const int kg8 = tid & 7;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float cs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+  for (int b0 = 0; b0 < a.Bt; b0 += 64) {
+    if (b0) __syncthreads();
+    uint4 pv[2], qv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int row = (tid + i * 256) >> 3;
+      bool v = (b0 + row) < a.Bt;
+      pv[i] = fc_load_a<PMODE>(a.p, (size_t)(b0 + row) * a.I + i0 + kg8 * 8, v, a.p.coef, (i0 + kg8 * 8) & 255);
+      qv[i] = fc_load_a<QMODE>(a.q, (size_t)(b0 + row) * a.J + j0 + kg8 * 8, v, a.q.coef, (j0 + kg8 * 8) & 255);
+      float f[8];
+      unpack8(pv[i], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cs[j] += f[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<uint4*>(pl + ((tid + i * 256) >> 3) * FC_LS + kg8 * 8) = pv[i];
+      *reinterpret_cast<uint4*>(ql + ((tid + i * 256) >> 3) * FC_LS + kg8 * 8) = qv[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r_lo = ks * 32 + 8 * g + q, r_hi = r_lo + 4;
+      bf16x8 pa = tr_frag(pl + r_lo * FC_LS + wave * 16 + 4 * p, pl + r_hi * FC_LS + wave * 16 + 4 * p);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        bf16x8 qb = tr_frag(ql + r_lo * FC_LS + jt * 16 + 4 * p, ql + r_hi * FC_LS + jt * 16 + 4 * p);
+        acc[jt] = mfma16(pa, qb, acc[jt]);
+      }
+    }
+  }
+  const int Pn = a.Pn;
+  auto perm = [=](int k2) -> int { return (k2 & 255) * Pn + (k2 >> 8); };
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int i = i0 + wave * 16 + (lane >> 4) * 4 + r;
+      int j = j0 + jt * 16 + (lane & 15);
+      size_t o = (a.out_mode == 0) ? (size_t)perm(i) * a.J + j : (size_t)i * a.J + perm(j);
+      a.out[o] = acc[jt][r];
+    }
+  if (a.colsum && blockIdx.y == 0) {
+    // thread (row-group tid>>3, chunk kg8) holds partial column sums of its rows; reduce over the 32 row-groups
+#pragma unroll
+    for (int j = 0; j < 8; ++j) csum[tid >> 3][kg8 * 8 + j] = cs[j];
+    __syncthreads();
+    if (tid < 64) {
+      float s = 0.f;
+      for (int r = 0; r < 32; ++r) s += csum[r][tid];
+      int i = i0 + tid;
+      a.colsum[a.out_mode == 0 ? perm(i) : i] = s;
+    }
+  }
+}

@@ -1,0 +1,33 @@
+// Host-side dispatch of the latent-projection GEMMs.
+#include "eae_internal.h"
+#include "eae_fc.cuh"
+
+int eae_launch_fc_nt(hipStream_t st, const FcNtArgs& a, int amode, int epi, int ksplit) {
+  if (a.N % 64 || a.K % 64 || a.klen % 64 || a.klen * ksplit != a.K) return eae_set_error(-2, "fc_nt: N, K, klen must be multiples of 64");
+  if (epi != FCE_PARTIAL && (a.N % 256 || ksplit != 1)) return eae_set_error(-2, "fc_nt: fused epilogues need N % 256 == 0 and no split-K");
+  dim3 grid((a.M + 127) / 128, a.N / 64, ksplit);
+#define CASE(AM, E) if (amode == AM && epi == E) { hipLaunchKernelGGL((fc_nt_kernel<AM, E>), grid, dim3(256), 0, st, a); EAE_LAUNCH_CHECK(); return 0; }
+  CASE(SRC_BNRELU, FCE_PARTIAL)     // enc.fc forward
+  CASE(SRC_RAW, FCE_PARTIAL)        // dec.fc backward-data
+  CASE(SRC_F32, FCE_BIAS_BF16)      // dec.fc forward
+  CASE(SRC_F32, FCE_MASK)           // enc.fc backward-data
+#undef CASE
+  return eae_set_error(-2, "fc_nt: combination not instantiated");
+}
+
+int eae_launch_fc_reduce(hipStream_t st, const float* part, int nsl, int M, int N, const float* bias, const float* addend, float* out) {
+  long n = (long)M * N;
+  hipLaunchKernelGGL(fc_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, nsl, M, N, bias, addend, out);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int eae_launch_fc_tn(hipStream_t st, const FcTnArgs& a, int pmode, int qmode) {
+  if (a.I % 64 || a.J % 64) return eae_set_error(-2, "fc_tn: I and J must be multiples of 64");
+  dim3 grid(a.I / 64, a.J / 64);
+#define CASE(PM, QM) if (pmode == PM && qmode == QM) { hipLaunchKernelGGL((fc_tn_kernel<PM, QM>), grid, dim3(256), 0, st, a); EAE_LAUNCH_CHECK(); return 0; }
+  CASE(SRC_RAW, SRC_F32)       // dec.fc weight gradient: P = g_d0, Q = z
+  CASE(SRC_F32, SRC_BNRELU)    // enc.fc weight gradient: P = dz,   Q = BNRELU(y4)
+#undef CASE
+  return eae_set_error(-2, "fc_tn: combination not instantiated");
+}

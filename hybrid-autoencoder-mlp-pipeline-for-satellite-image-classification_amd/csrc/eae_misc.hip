@@ -1,0 +1,225 @@
+// Small kernels: BatchNorm finalisation (forward statistics -> apply coefficients + running stats, backward
+// reductions -> dgamma/dbeta + apply coefficients), weight packing (fp32 master -> bf16 kernel layouts),
+// fused multi-tensor Adam, loss bookkeeping.
+#include "eae_internal.h"
+#include "eae_common.cuh"
+#include "eae_misc.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm forward finalize.  part = [ntiles][2][C] (sum y, sum y^2) -> coef [4][C] = s, t, mean, invstd
+//   s = gamma*invstd, t = beta - mean*s  so that  BN(y) = s*y + t           (nn.BatchNorm2d, eps 1e-5, R.md:293)
+// running_mean/var updated with momentum (unbiased variance), num_batches_tracked += 1   
+// grid = ceil(C/16) blocks of 256 threads: 16 channels x 16 strided tile lanes, fixed summation order.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int ntiles, int C, float count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* running_mean, float* running_var, long long* nbt,
+                                                           float momentum, float eps, float* __restrict__ coef) {
+  __shared__ double r1[16][17], r2[16][17];
+  const int tid = threadIdx.x, cl = tid & 15, tl = tid >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (ch < C)
+    for (int t = tl; t < ntiles; t += 16) {
+      s1 += (double)part[((size_t)t * 2 + 0) * C + ch];
+      s2 += (double)part[((size_t)t * 2 + 1) * C + ch];
+    }
+  r1[tl][cl] = s1; r2[tl][cl] = s2;
+  __syncthreads();
+  if (tid < 16 && ch < C) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < 16; ++i) { a += r1[i][cl]; b += r2[i][cl]; }
+    double mean = a / count;
+    double var = b / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float invstd = 1.0f / sqrtf((float)var + eps);
+    float s = gamma[ch] * invstd;
+    coef[ch] = s;
+    coef[C + ch] = beta[ch] - (float)mean * s;
+    coef[2 * C + ch] = (float)mean;
+    coef[3 * C + ch] = invstd;
+    if (running_mean) {
+      double unb = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+      running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
+      running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+    }
+  }
+  if (nbt && blockIdx.x == 0 && tid == 0) *nbt += 1;
+}
+
+// eval mode: coefficients from the running statistics
+__global__ void bn_eval_coef_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                    float* coef) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= C) return;
+  float invstd = 1.0f / sqrtf(rv[ch] + eps);
+  float s = gamma[ch] * invstd;
+  coef[ch] = s;
+  coef[C + ch] = beta[ch] - rm[ch] * s;
+  coef[2 * C + ch] = rm[ch];
+  coef[3 * C + ch] = invstd;
+}
+
+// BatchNorm backward finalize.  part = [ntiles][2][C] (sum g, sum g*xhat), g = ReLU-masked upstream gradient.
+//   dbeta = sum g ; dgamma = sum g*xhat ;  dy = A*g + B*y + Cc  with
+//   A = gamma*invstd, B = -A*invstd*dgamma/N, Cc = -A*dbeta/N + A*invstd*mean*dgamma/N   (native_batch_norm_backward)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int ntiles, int C, float count,
+                                                               const float* __restrict__ gamma, const float* __restrict__ coef_fwd,
+                                                               float* dgamma, float* dbeta, float* __restrict__ coef_bwd) {
+  __shared__ double r1[16][17], r2[16][17];
+  const int tid = threadIdx.x, cl = tid & 15, tl = tid >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (ch < C)
+    for (int t = tl; t < ntiles; t += 16) {
+      s1 += (double)part[((size_t)t * 2 + 0) * C + ch];
+      s2 += (double)part[((size_t)t * 2 + 1) * C + ch];
+    }
+  r1[tl][cl] = s1; r2[tl][cl] = s2;
+  __syncthreads();
+  if (tid < 16 && ch < C) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < 16; ++i) { a += r1[i][cl]; b += r2[i][cl]; }
+    float db = (float)a, dg = (float)b;
+    if (dbeta) dbeta[ch] = db;
+    if (dgamma) dgamma[ch] = dg;
+    float mean = coef_fwd[2 * C + ch], invstd = coef_fwd[3 * C + ch];
+    float A = gamma[ch] * invstd;
+    float Bc = -A * invstd * dg / count;
+    coef_bwd[ch] = A;
+    coef_bwd[C + ch] = Bc;
+    coef_bwd[2 * C + ch] = -A * db / count - Bc * mean;
+  }
+}
+
+int eae_launch_bn_finalize(hipStream_t st, const float* part, int ntiles, int C, long long count, const float* gamma,
+                           const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, ntiles, C, (float)count, gamma, beta, rm,
+                     rv, nbt, momentum, eps, coef);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+int eae_launch_bn_eval_coef(hipStream_t st, int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                            float eps, float* coef) {
+  hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, C, gamma, beta, rm, rv, eps, coef);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+int eae_launch_bn_bwd_finalize(hipStream_t st, const float* part, int ntiles, int C, long long count, const float* gamma,
+                               const float* coef_fwd, float* dgamma, float* dbeta, float* coef_bwd) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, ntiles, C, (float)count, gamma,
+                     coef_fwd, dgamma, dbeta, coef_bwd);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight packing: one launch converts every fp32 master weight into the bf16 layouts the kernels read.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pack_fetch(const PackDesc& d, const float* __restrict__ src, long i) {
+  switch (d.mode) {
+    case PACK_3x3_P1: {   // dst [A][9][B]  <- src [A][B][3][3]
+      int b = i % d.d1; long r = i / d.d1; int tap = r % 9; int a = r / 9;
+      return src[((long)a * d.d1 + b) * 9 + tap];
+    }
+    case PACK_3x3_P2: {   // dst [B][9][A]  <- src [A][B][3][3]
+      int a = i % d.d0; long r = i / d.d0; int tap = r % 9; int b = r / 9;
+      return src[((long)a * d.d1 + b) * 9 + tap];
+    }
+    case PACK_K27: {      // dst [A][32] with k = tap*3 + c (zero for k >= 27)  <- src [A][3][3][3]
+      int k = i & 31; int a = i >> 5;
+      if (k >= 27) return 0.f;
+      int tap = k / 3, c = k % 3;
+      return src[((long)a * 3 + c) * 9 + tap];
+    }
+    case PACK_DECONV4_JOINT: {   // dst [16][128]: n = phase*3+co, k = nb*32+ci  <- src [32 ci][3 co][3][3]
+      int k = i & 127; int n = i >> 7;
+      if (n >= 12) return 0.f;
+      int ph = n / 3, co = n % 3, nb = k >> 5, ci = k & 31;
+      int py = ph >> 1, px = ph & 1, dy = nb >> 1, dx = nb & 1;
+      int ky = py == 0 ? (dy == 0 ? 1 : -1) : (dy == 0 ? 2 : 0);
+      int kx = px == 0 ? (dx == 0 ? 1 : -1) : (dx == 0 ? 2 : 0);
+      if (ky < 0 || kx < 0) return 0.f;
+      return src[((long)ci * 3 + co) * 9 + ky * 3 + kx];
+    }
+    case PACK_FC_ROWMAJOR_KPERM: {   // dst [R][K'] with k' = p*Cc + c  <- src [R][K] with k = c*P + p   (d0=R, d1=Cc, d2=P)
+      long K = (long)d.d1 * d.d2; long k2 = i % K; int r = i / K;
+      int c = k2 % d.d1, p = k2 / d.d1;
+      return src[(long)r * K + (long)c * d.d2 + p];
+    }
+    case PACK_FC_TRANS_KPERM: {      // dst [K'][R]  <- src [R][K]   (transpose + permute)
+      int r = i % d.d0; long k2 = i / d.d0;
+      long K = (long)d.d1 * d.d2;
+      int c = k2 % d.d1, p = k2 / d.d1;
+      return src[(long)r * K + (long)c * d.d2 + p];
+    }
+    case PACK_FC_ROWPERM: {          // dst [J'][L] with j' = p*Cc + c <- src [J][L] with j = c*P + p   (d0=L, d1=Cc, d2=P)
+      int l = i % d.d0; long j2 = i / d.d0;
+      int c = j2 % d.d1, p = j2 / d.d1;
+      return src[((long)c * d.d2 + p) * d.d0 + l];
+    }
+    case PACK_FC_ROWPERM_TRANS: {    // dst [L][J']  <- src [J][L]
+      long J = (long)d.d1 * d.d2; long j2 = i % J; int l = i / J;
+      int c = j2 % d.d1, p = j2 / d.d1;
+      return src[((long)c * d.d2 + p) * d.d0 + l];
+    }
+    default: return src[i];          // PACK_COPY
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackDesc* __restrict__ descs, const float* __restrict__ params,
+                                                        uint8_t* __restrict__ pack_base) {
+  const PackDesc d = descs[blockIdx.y];
+  const float* src = params + d.src_off;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < d.count; i += (long)gridDim.x * 256) {
+    float v = pack_fetch(d, src, i);
+    if (d.out_f32) reinterpret_cast<float*>(pack_base + d.dst_off)[i] = v;
+    else reinterpret_cast<bf16_t*>(pack_base + d.dst_off)[i] = (bf16_t)f2bf(v);
+  }
+}
+
+int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base) {
+  hipLaunchKernelGGL(pack_all_kernel, dim3(32, ndesc), dim3(256), 0, st, descs_dev, params, (uint8_t*)pack_base);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused multi-tensor Adam over the flat fp32 arenas (torch.optim.Adam defaults, R.md:624; L2 decay for the MLP, R.md:2625)
+//   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n4, float b1, float b2, float step_size,
+                                                    float bc2_sqrt, float eps, float wd) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gj = G[j] + wd * P[j];
+      M[j] = M[j] + (1.f - b1) * (gj - M[j]);            // exp_avg.lerp_(grad, 1-beta1)
+      V[j] = b2 * V[j] + (1.f - b2) * gj * gj;            // mul_(beta2).addcmul_(grad, grad, 1-beta2)
+      float denom = sqrtf(V[j]) / bc2_sqrt + eps;
+      P[j] -= step_size * (M[j] / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+}
+
+int eae_launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
+                    double eps, double wd, long long step) {
+  if (n % 4) return eae_set_error(-2, "adam: arena length must be a multiple of 4");
+  double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+  long n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4, (float)b1, (float)b2, (float)(lr / bc1),
+                     (float)sqrt(bc2), (float)eps, (float)wd);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}

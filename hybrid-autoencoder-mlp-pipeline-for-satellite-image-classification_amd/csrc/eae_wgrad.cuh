@@ -1,0 +1,167 @@
+// Weight-gradient kernel of the 3x3 stride-2 conv / transposed-conv layers (aten::convolution_backward's wgrad,
+// 39 % of the reference's CPU step time).
+//
+//   R[tap][cs][cb] = sum over positions (n,oy,ox) of  S[n,oy,ox,cs] * Bg[n,2oy-1+ky,2ox-1+kx,cb]
+//
+//   conv   layer: S = dy (gradient of the conv output, small map), Bg = input activation (big map)  -> dW[co=cs][ci=cb][ky][kx]
+//   deconv layer: S = input activation (small map), Bg = gradient of the deconv output (big map)    -> dW[ci=cs][co=cb][ky][kx]
+// i.e. both land directly in the reference's parameter layout [cs][cb][3][3].
+//
+// The reduction runs over pixels, which are the *strided* dimension of NHWC tensors, so both MFMA operands are read
+// with the hardware transposing LDS read (ds_read_b64_tr_b16): the S tile and the Bg patch sit in LDS in their natural
+// [pixel][channel] order (staged with 16-byte loads, load transforms applied once per element) and each lane supplies
+// the addresses of the gathered patch rows of its tap.
+// One block owns a (64 cs) x (32 cb) x 9-tap output block and a slice of the positions; it writes an fp32 partial in
+// the reference layout, partials are summed in a fixed order by reduce_slices_kernel (deterministic, no atomics).
+#pragma once
+#include "eae_common.cuh"
+#include "eae_conv.cuh"
+
+struct WgradArgs {
+  SrcDesc small, big;
+  float* part;            // [nslices][CS*CB*9]
+  int B, Hs, Ws;          // small-map spatial size (big map = 2Hs x 2Ws)
+  int tiles_per_block, ntiles;
+};
+
+constexpr int S_STRIDE = 72;   // bf16 elements per staged S row: 64 channels + 8 pad (144 B)
+
+template <int CS, int CB, int TW, int TH, int NI, int SMODE, int BMODE>
+__global__ __launch_bounds__(256) void wgrad_s2_kernel(WgradArgs a) {
+  static_assert(NI * TH * TW == 128, "tile must hold 128 positions");
+  static_assert(CS % 64 == 0 && CB % 32 == 0, "shape");
+  constexpr int PH = 2 * TH + 1, PW = 2 * TW + 1, NPIX = NI * PH * PW;
+  constexpr int NPA = (NPIX * 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  bf16_t* patch = smem;                          // [NPIX][PIX_STRIDE]
+  bf16_t* sl = smem + NPIX * PIX_STRIDE;         // [128][S_STRIDE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cs0 = (blockIdx.y / (CB / 32)) * 64, cb0 = (blockIdx.y % (CB / 32)) * 32;
+  const int Hb = a.Hs * 2, Wb = a.Ws * 2;
+  const int tiles_x = a.Ws / TW, tiles_y = a.Hs / TH;
+  const int kgs4 = tid & 3, kgs8 = tid & 7;
+  ChanCoef<BMODE> ccb;
+  ccb.load(a.big.coef, CB, cb0 + kgs4 * 8);
+  ChanCoef<SMODE> ccs;
+  ccs.load(a.small.coef, CS, cs0 + kgs8 * 8);
+  // wave: cs-tiles {2*(wave&1), +1} x cb-tile (wave>>1) x 9 taps
+  const int it0 = 2 * (wave & 1), jt = wave >> 1;
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9) acc[t9][0] = acc[t9][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+
+  for (int ti = 0; ti < a.tiles_per_block; ++ti) {
+    int t = blockIdx.x * a.tiles_per_block + ti;
+    if (t >= a.ntiles) break;
+    const int txb = t % tiles_x; t /= tiles_x;
+    const int tyb = t % tiles_y; t /= tiles_y;
+    const int img0 = t * NI;
+    const int iy0 = 2 * tyb * TH - 1, ix0 = 2 * txb * TW - 1;
+    __syncthreads();
+    // ---- big-map patch (32 channels cb0..cb0+31)
+    RawPiece<BMODE> raw[NPA];
+    bool val[NPA];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      int qq = tid + i * 256;
+      int pix = qq >> 2;
+      int img = pix / (PH * PW), rem = pix % (PH * PW);
+      int pr = rem / PW, pc = rem % PW;
+      int iy = iy0 + pr, ix = ix0 + pc, n = img0 + img;
+      val[i] = (pix < NPIX) && (n < a.B) && (iy >= 0) && (iy < Hb) && (ix >= 0) && (ix < Wb);
+      size_t off = (((size_t)n * Hb + iy) * Wb + ix) * CB + cb0 + kgs4 * 8;
+      load_piece<BMODE>(a.big, off, val[i], raw[i]);
+    }
+    // ---- small-map tile [128 positions][64 channels cs0..]
+    RawPiece<SMODE> sraw[4];
+    bool sval[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int qq = tid + i * 256;
+      int m = qq >> 3;
+      int img = m / (TH * TW), ty = (m / TW) % TH, tx = m % TW;
+      int n = img0 + img;
+      sval[i] = n < a.B;
+      size_t off = (((size_t)n * a.Hs + tyb * TH + ty) * a.Ws + txb * TW + tx) * CS + cs0 + kgs8 * 8;
+      load_piece<SMODE>(a.small, off, sval[i], sraw[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      int qq = tid + i * 256;
+      if (qq < NPIX * 4)
+        *reinterpret_cast<uint4*>(patch + (qq >> 2) * PIX_STRIDE + kgs4 * 8) = transform_piece<BMODE>(raw[i], val[i], ccb);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int qq = tid + i * 256;
+      *reinterpret_cast<uint4*>(sl + (qq >> 3) * S_STRIDE + kgs8 * 8) = transform_piece<SMODE>(sraw[i], sval[i], ccs);
+    }
+    __syncthreads();
+    // ---- 4 K-steps of 32 positions
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int m_lo = ks * 32 + 8 * g + q, m_hi = m_lo + 4;
+      bf16x8 sa[2];
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+        sa[ii] = tr_frag(sl + m_lo * S_STRIDE + (it0 + ii) * 16 + 4 * p, sl + m_hi * S_STRIDE + (it0 + ii) * 16 + 4 * p);
+      int pb_lo, pb_hi;
+      {
+        int img = m_lo / (TH * TW), ty = (m_lo / TW) % TH, tx = m_lo % TW;
+        pb_lo = (img * PH + 2 * ty) * PW + 2 * tx;
+        img = m_hi / (TH * TW); ty = (m_hi / TW) % TH; tx = m_hi % TW;
+        pb_hi = (img * PH + 2 * ty) * PW + 2 * tx;
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int toff = (tap / 3) * PW + (tap % 3);
+        bf16x8 bb = tr_frag(patch + (pb_lo + toff) * PIX_STRIDE + jt * 16 + 4 * p,
+                            patch + (pb_hi + toff) * PIX_STRIDE + jt * 16 + 4 * p);
+        acc[tap][0] = mfma16(sa[0], bb, acc[tap][0]);
+        acc[tap][1] = mfma16(sa[1], bb, acc[tap][1]);
+      }
+    }
+  }
+  // ---- store the partial in reference layout [cs][cb][9]
+  float* out = a.part + (size_t)blockIdx.x * ((size_t)CS * CB * 9);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int cs = cs0 + (it0 + ii) * 16 + (lane >> 4) * 4 + r;
+        int cb = cb0 + jt * 16 + (lane & 15);
+        out[((size_t)cs * CB + cb) * 9 + tap] = acc[tap][ii][r];
+      }
+}
+
+template <int TW, int TH, int NI>
+constexpr size_t wgrad_smem() {
+  constexpr int PH = 2 * TH + 1, PW = 2 * TW + 1, NPIX = NI * PH * PW;
+  return (size_t)(NPIX * PIX_STRIDE + 128 * S_STRIDE) * 2;
+}
+
+// out[i] = sum_s part[s][i]   (fixed order).  block (64,4): 64 float4 lanes x 4 slice lanes.
+static __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ part, int nslices, long n4,
+                                                             float* __restrict__ out, float scale) {
+  __shared__ float4 red[4][64];
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + lx;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4)
+    for (int sidx = ly; sidx < nslices; sidx += 4) {
+      float4 v = reinterpret_cast<const float4*>(part)[(long)sidx * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  red[ly][lx] = s;
+  __syncthreads();
+  if (ly == 0 && i < n4) {
+    float4 r = red[0][lx];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { r.x += red[k][lx].x; r.y += red[k][lx].y; r.z += red[k][lx].z; r.w += red[k][lx].w; }
+    r.x *= scale; r.y *= scale; r.z *= scale; r.w *= scale;
+    reinterpret_cast<float4*>(out)[i] = r;
+  }
+}

@@ -1,0 +1,59 @@
+// Host-side dispatch of the generic 3x3 stride-2 weight-gradient kernel.
+#include "eae_internal.h"
+#include "eae_wgrad.cuh"
+
+namespace {
+template <int CS, int CB, int TW, int TH, int NI, int SM, int BM>
+int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_floats, float* dw, hipStream_t st) {
+  WgradArgs a = a0;
+  constexpr int nblk = (CS / 64) * (CB / 32);
+  constexpr long long sz = (long long)CS * CB * 9;
+  int slices = 256 / nblk;
+  if (slices < 1) slices = 1;
+  if (slices > ntiles) slices = ntiles;
+  while ((long long)slices * sz > scratch_floats && slices > 1) slices >>= 1;
+  if ((long long)slices * sz > scratch_floats) return eae_set_error(-2, "wgrad: scratch too small");
+  a.ntiles = ntiles;
+  a.tiles_per_block = (ntiles + slices - 1) / slices;
+  slices = (ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
+  a.part = scratch;
+  auto kern = wgrad_s2_kernel<CS, CB, TW, TH, NI, SM, BM>;
+  constexpr size_t smem = wgrad_smem<TW, TH, NI>();
+  static bool done = false;
+  if (!done) {
+    EAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(slices, nblk), dim3(256), smem, st, a);
+  EAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((sz / 4 + 63) / 64)), dim3(256), 0, st, scratch, slices, (long)(sz / 4), dw, 1.0f);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int CS, int CB, int SM, int BM>
+int geo(const WgradArgs& a, float* scratch, long long sf, float* dw, hipStream_t st) {
+  if (a.Ws % 16 == 0 && a.Hs % 8 == 0) return launch<CS, CB, 16, 8, 1, SM, BM>(a, a.B * (a.Hs / 8) * (a.Ws / 16), scratch, sf, dw, st);
+  if (a.Ws == 8 && a.Hs == 8) return launch<CS, CB, 8, 8, 2, SM, BM>(a, (a.B + 1) / 2, scratch, sf, dw, st);
+  if (a.Ws == 4 && a.Hs == 4) return launch<CS, CB, 4, 4, 8, SM, BM>(a, (a.B + 7) / 8, scratch, sf, dw, st);
+  return eae_set_error(-2, "wgrad: unsupported spatial size");
+}
+}  // namespace
+
+// instantiations used by the path
+//   conv2/3/4   : small = dy  (BNBWD), big = input activation (BNRELU): (64,32) (128,64) (256,128)
+//   deconv3/2   : small = input activation (BNRELU), big = dOut (BNBWD): (64,32) (128,64)
+//   deconv1     : small = dec.fc output (RAW),      big = dOut (BNBWD): (256,128)
+int eae_launch_wgrad_s2(hipStream_t st, const WgradArgs& a, int cs, int cb, int smode, int bmode, float* scratch,
+                        long long scratch_floats, float* dw) {
+#define CASE(S, B_, SM, BM) if (cs == S && cb == B_ && smode == SM && bmode == BM) return geo<S, B_, SM, BM>(a, scratch, scratch_floats, dw, st)
+  CASE(64, 32, SRC_BNBWD, SRC_BNRELU);
+  CASE(128, 64, SRC_BNBWD, SRC_BNRELU);
+  CASE(256, 128, SRC_BNBWD, SRC_BNRELU);
+  CASE(64, 32, SRC_BNRELU, SRC_BNBWD);
+  CASE(128, 64, SRC_BNRELU, SRC_BNBWD);
+  CASE(256, 128, SRC_RAW, SRC_BNBWD);
+  CASE(64, 32, SRC_RAW, SRC_RAW);       // plain (tests)
+#undef CASE
+  return eae_set_error(-2, "wgrad: no kernel instantiated for this (cs, cb, modes)");
+}

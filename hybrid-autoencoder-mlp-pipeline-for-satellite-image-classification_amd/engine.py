@@ -1,0 +1,294 @@
+"""Host side of the HIP engine: flat parameter arenas, the C context, and the step entry points.
+
+The reference keeps every parameter as its own tensor and lets autograd + ``torch.optim.Adam`` walk them
+(R.md:624, 646-654).  Here the 38 tensors of ``SupervisedAutoencoder`` live in ONE flat fp32 arena (plus
+gradient / Adam-moment arenas of the same layout) so that the fused multi-tensor Adam kernel and the
+data-parallel all-reduce see a single buffer; the module's ``nn.Parameter``s are re-pointed to views of the
+arena, so ``state_dict()`` / ``load_state_dict()`` / ``.parameters()`` keep working unchanged.
+
+PyTorch is used for device memory, streams and (in ``dp.py``) ``torch.distributed`` only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import torch
+
+from . import _lib
+from ._lib import EaeConfig, EaeStepIO, check
+
+_ENGINES = weakref.WeakKeyDictionary()
+
+
+def _ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu(device):
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise RuntimeError("the autoencoder engine runs on a HIP device only (model.to('cuda')); there is no CPU path")
+
+
+class AEEngine:
+    """Owns the arenas + C context of one SupervisedAutoencoder (or a stand-alone Encoder / Decoder)."""
+
+    def __init__(self, root, max_batch=512):
+        from .modules import SupervisedAutoencoder, Encoder, Decoder
+        self.lib = _lib.load()
+        self.root_ref = weakref.ref(root)
+        if isinstance(root, SupervisedAutoencoder):
+            enc, dec, cls = root.enc, root.dec, root.classifier
+            latent, classes, size = root.latent_dim, root.num_classes, root.enc.image_size
+        elif isinstance(root, Encoder):
+            enc, dec, cls, latent, classes, size = root, None, None, root.latent_dim, 10, root.image_size
+        elif isinstance(root, Decoder):
+            enc, dec, cls, latent, classes, size = None, root, None, root.latent_dim, 10, root.image_size
+        else:
+            raise TypeError(type(root))
+        self.latent, self.classes, self.size = latent, classes, size
+        p0 = next(root.parameters())
+        self.device = p0.device
+        _require_gpu(self.device)
+        self.cfg = EaeConfig(latent, classes, size, size, int(max_batch))
+        self.max_batch = int(max_batch)
+        poff = (C.c_longlong * 39)()
+        boff = (C.c_longlong * 15)()
+        check(self.lib.eae_ae_layout(C.byref(self.cfg), poff, boff))
+        self.poff, self.boff = list(poff), list(boff)
+        n = self.poff[38]
+        with torch.cuda.device(self.device):
+            self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.grads = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.adam_m = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.adam_v = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.bn_running = torch.zeros(self.boff[14], dtype=torch.float32, device=self.device)
+            self.bn_nbt = torch.zeros(7, dtype=torch.int64, device=self.device)
+            self.loss_accum = torch.zeros(8, dtype=torch.float32, device=self.device)
+            self.loss_last = torch.zeros(4, dtype=torch.float32, device=self.device)
+        # slots: (module attribute path) in named_parameters() order of SupervisedAutoencoder
+        self._slots = []      # (param tensor holder, index)
+        self._bn_slots = []   # (bn module, l)
+        if enc is not None:
+            e = enc.encoder
+            for i, (ci, bi) in enumerate(((0, 1), (3, 4), (6, 7), (9, 10))):
+                self._slots += [(e[ci].weight, 4 * i), (e[ci].bias, 4 * i + 1), (e[bi].weight, 4 * i + 2), (e[bi].bias, 4 * i + 3)]
+                self._bn_slots.append((e[bi], i))
+            self._slots += [(e[13].weight, 16), (e[13].bias, 17)]
+        if dec is not None:
+            self._slots += [(dec.decoder_input.weight, 18), (dec.decoder_input.bias, 19)]
+            d = dec.decoder
+            for i, (di, bi) in enumerate(((1, 2), (4, 5), (7, 8))):
+                self._slots += [(d[di].weight, 20 + 4 * i), (d[di].bias, 21 + 4 * i), (d[bi].weight, 22 + 4 * i), (d[bi].bias, 23 + 4 * i)]
+                self._bn_slots.append((d[bi], 4 + i))
+            self._slots += [(d[10].weight, 32), (d[10].bias, 33)]
+        if cls is not None:
+            self._slots += [(cls[0].weight, 34), (cls[0].bias, 35), (cls[2].weight, 36), (cls[2].bias, 37)]
+        # BatchNorm of absent halves must still be well-defined (gamma=1, running_var=1)
+        for l, c in enumerate((32, 64, 128, 256, 128, 64, 32)):
+            self.bn_running[self.boff[2 * l + 1]: self.boff[2 * l + 1] + c] = 1.0
+            g = (2, 6, 10, 14, 22, 26, 30)[l]
+            self.params[self.poff[g]: self.poff[g] + c] = 1.0
+        self._adopt()
+        h = C.c_void_p()
+        check(self.lib.eae_create(C.byref(self.cfg), C.byref(h)))
+        self.ctx = h
+        check(self.lib.eae_bind(self.ctx, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
+                                _ptr(self.bn_running), _ptr(self.bn_nbt)))
+        self._finalizer = weakref.finalize(self, _destroy, self.lib, self.ctx)
+        root.register_load_state_dict_post_hook(lambda m, k: self.params_changed())
+
+    # ------------------------------------------------------------------ arena management
+    def _adopt(self):
+        """Copy the module's tensors into the arenas and re-point them to arena views."""
+        with torch.no_grad():
+            for p, i in self._slots:
+                n = p.numel()
+                view = self.params[self.poff[i]: self.poff[i] + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = None
+            for bn, l in self._bn_slots:
+                c = bn.num_features
+                rm = self.bn_running[self.boff[2 * l]: self.boff[2 * l] + c]
+                rv = self.bn_running[self.boff[2 * l + 1]: self.boff[2 * l + 1] + c]
+                rm.copy_(bn.running_mean)
+                rv.copy_(bn.running_var)
+                self.bn_nbt[l] = bn.num_batches_tracked.to(self.device)
+                bn._buffers["running_mean"] = rm
+                bn._buffers["running_var"] = rv
+                bn._buffers["num_batches_tracked"] = self.bn_nbt[l]
+
+    def attached(self):
+        """True while every parameter still aliases the arena (``.to()`` / ``.float()`` may replace them)."""
+        base = self.params.data_ptr()
+        for p, i in self._slots:
+            if p.data_ptr() != base + 4 * self.poff[i]:
+                return False
+        for bn, l in self._bn_slots:
+            if bn.running_mean.data_ptr() != self.bn_running.data_ptr() + 4 * self.boff[2 * l]:
+                return False
+        return True
+
+    def params_changed(self):
+        check(self.lib.eae_params_changed(self.ctx))
+
+    def expose_grads(self):
+        """Make ``p.grad`` of every parameter a view of the gradient arena (after a fused grad step)."""
+        for p, i in self._slots:
+            p.grad = self.grads[self.poff[i]: self.poff[i] + p.numel()].view(p.shape)
+
+    def grad_view(self, i, shape):
+        n = 1
+        for s in shape:
+            n *= s
+        return self.grads[self.poff[i]: self.poff[i] + n].view(shape)
+
+    # ------------------------------------------------------------------ steps
+    def _io(self, x, labels, train, head, alpha, x_hat=None, logits=None, z=None, accum=True):
+        if x.device != self.device or x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3 or \
+                x.shape[2] != self.size or x.shape[3] != self.size:
+            raise RuntimeError(f"expected float32 input [B,3,{self.size},{self.size}] on {self.device}, got "
+                               f"{tuple(x.shape)} {x.dtype} on {x.device}")
+        if not x.is_contiguous():
+            x = x.contiguous()
+        b = x.shape[0]
+        if b > self.max_batch:
+            raise RuntimeError(f"batch {b} exceeds the engine's max_batch {self.max_batch}")
+        if labels is not None:
+            if labels.dtype != torch.int64 or labels.shape != (b,) or labels.device != self.device:
+                raise RuntimeError("labels must be int64 [B] on the model's device")
+            labels = labels.contiguous()
+        io = EaeStepIO(_ptr(x), _ptr(labels), b, int(train), int(head), float(alpha), _ptr(x_hat), _ptr(logits), _ptr(z),
+                       _ptr(self.loss_accum) if accum else None, _ptr(self.loss_last))
+        return io, (x, labels)
+
+    def forward(self, x, labels=None, train=False, head=True, alpha=1.0, want=("x_hat", "logits", "z"), accum=False):
+        b = x.shape[0]
+        x_hat = torch.empty((b, 3, self.size, self.size), dtype=torch.float32, device=self.device) if "x_hat" in want else None
+        logits = torch.empty((b, self.classes), dtype=torch.float32, device=self.device) if ("logits" in want and head) else None
+        z = torch.empty((b, self.latent), dtype=torch.float32, device=self.device) if "z" in want else None
+        io, keep = self._io(x, labels, train, head, alpha, x_hat, logits, z, accum)
+        check(self.lib.eae_ae_forward(self.ctx, _stream(), C.byref(io)))
+        return x_hat, logits, z
+
+    def grad_step(self, x, labels, alpha, head=True, x_hat=None):
+        io, keep = self._io(x, labels, True, head, alpha, x_hat)
+        check(self.lib.eae_ae_grad_step(self.ctx, _stream(), C.byref(io)))
+
+    def adam_step(self, lr, weight_decay=0.0):
+        check(self.lib.eae_adam_step(self.ctx, _stream(), float(lr), float(weight_decay)))
+
+    def train_step(self, x, labels, alpha, lr, head=True, x_hat=None):
+        """One iteration of the reference's batch loop (R.md:646-657); the loss is accumulated on the device."""
+        io, keep = self._io(x, labels, True, head, alpha, x_hat)
+        check(self.lib.eae_ae_train_step(self.ctx, _stream(), C.byref(io), float(lr)))
+
+    def encoder(self, x, train=False):
+        b = x.shape[0]
+        z = torch.empty((b, self.latent), dtype=torch.float32, device=self.device)
+        io, keep = self._io(x, None, train, False, 1.0)
+        check(self.lib.eae_encoder_forward(self.ctx, _stream(), _ptr(keep[0]), b, int(train), _ptr(z)))
+        return z
+
+    def decoder(self, z, train=False):
+        if z.device != self.device or z.dtype != torch.float32 or z.dim() != 2 or z.shape[1] != self.latent:
+            raise RuntimeError(f"expected float32 latent [B,{self.latent}] on {self.device}")
+        z = z.contiguous()
+        b = z.shape[0]
+        if b > self.max_batch:
+            raise RuntimeError(f"batch {b} exceeds the engine's max_batch {self.max_batch}")
+        x_hat = torch.empty((b, 3, self.size, self.size), dtype=torch.float32, device=self.device)
+        check(self.lib.eae_decoder_forward(self.ctx, _stream(), _ptr(z), b, int(train), _ptr(x_hat)))
+        return x_hat
+
+    def reset_optimizer(self):
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        check(self.lib.eae_set_adam_step(self.ctx, 0))
+
+    def reset_loss(self):
+        self.loss_accum.zero_()
+
+    def read_loss(self):
+        """(mean loss, mean mse, mean ce, n samples, n correct) accumulated since reset_loss(); one D2H sync."""
+        a = self.loss_accum.tolist()
+        n = max(a[3], 1.0)
+        return a[0] / n, a[1] / n, a[2] / n, int(a[3]), int(a[4])
+
+
+def _destroy(lib, ctx):
+    try:
+        lib.eae_destroy(ctx)
+    except Exception:
+        pass
+
+
+_PARENTS = weakref.WeakKeyDictionary()     # Encoder / Decoder instance -> weakref(SupervisedAutoencoder that owns it)
+
+
+def register_children(parent, children):
+    for ch in children:
+        _PARENTS[ch] = weakref.ref(parent)
+
+
+def _root_of(module):
+    parent = _PARENTS.get(module)
+    if parent is not None:
+        p = parent()
+        if p is not None:
+            return p
+    return module
+
+
+def engine_for(module, max_batch=None):
+    """Engine of the SupervisedAutoencoder that owns `module` (or of a stand-alone Encoder / Decoder)."""
+    root = _root_of(module)
+    eng = _ENGINES.get(root)
+    dev = next(root.parameters()).device
+    _require_gpu(dev)
+    want_mb = max_batch or getattr(root, "_eae_max_batch", 512)
+    if eng is not None and (not eng.attached() or eng.device != dev or eng.max_batch < want_mb):
+        eng = None     # parameters were moved / re-created: rebuild the arenas from the module's current tensors
+    if eng is None:
+        eng = AEEngine(root, max_batch=want_mb)
+        _ENGINES[root] = eng
+    return eng
+
+
+class _ModuleFacade:
+    """What the nn.Module shells call (modules.py).  Inference / no-grad forward of the reference signatures."""
+
+    @staticmethod
+    def _check_grad(module, *tensors):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+            raise RuntimeError(
+                "differentiating through Module.forward with an external torch loss is not supported by the HIP engine "
+                "yet: use eae_amd.train.train_step / fit_autoencoder (fused alpha*MSE + CE step, R.md:646-654), or call "
+                "forward under torch.no_grad()")
+
+
+def autoencoder_forward(module, x):
+    _ModuleFacade._check_grad(module)
+    eng = engine_for(module)
+    eng.params_changed()
+    x_hat, logits, z = eng.forward(x, train=module.training, head=True)
+    return x_hat, logits, z
+
+
+def encoder_forward(module, x):
+    _ModuleFacade._check_grad(module)
+    eng = engine_for(module)
+    eng.params_changed()
+    return eng.encoder(x, train=module.training)
+
+
+def decoder_forward(module, z):
+    _ModuleFacade._check_grad(module)
+    eng = engine_for(module)
+    eng.params_changed()
+    return eng.decoder(z, train=module.training)

@@ -59,9 +59,9 @@ class _Marker(nn.Module):
     forward = _no_forward
 
 
-def _engine_for(owner):
-    from .engine import engine_for
-    return engine_for(owner)
+def _engine():
+    from . import engine
+    return engine
 
 
 class Encoder(nn.Module):
@@ -82,7 +82,7 @@ class Encoder(nn.Module):
         )
 
     def forward(self, x):
-        return _engine_for(self).encoder_forward(self, x)
+        return _engine().encoder_forward(self, x)
 
 
 class Decoder(nn.Module):
@@ -104,7 +104,7 @@ class Decoder(nn.Module):
         )
 
     def forward(self, z):
-        return _engine_for(self).decoder_forward(self, z)
+        return _engine().decoder_forward(self, z)
 
 
 class SupervisedAutoencoder(nn.Module):
@@ -121,9 +121,10 @@ class SupervisedAutoencoder(nn.Module):
             _Marker("ReLU"),
             LinearParams(128, self.num_classes),
         )
+        _engine().register_children(self, (self.enc, self.dec))
 
     def forward(self, x):
-        return _engine_for(self).autoencoder_forward(self, x)
+        return _engine().autoencoder_forward(self, x)
 
 
 class MLP(nn.Module):
@@ -145,4 +146,5 @@ class MLP(nn.Module):
         )
 
     def forward(self, x):
-        return _engine_for(self).mlp_forward(self, x)
+        from . import mlp_engine
+        return mlp_engine.mlp_forward(self, x)

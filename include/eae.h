@@ -1,0 +1,152 @@
+/* eae.h -- C ABI of libeae.so: the MI355X (gfx950) engine behind the notebook's Encoder / Decoder /
+ * SupervisedAutoencoder / MLP modules and its fit / evaluate loops.
+ *
+ * The reference has no FFI for this path: its boundary is the Python class surface of the notebook
+ * (R.md = /root/reference/Report/Hybrid_autoencoder–MLP_pipeline_for_satellite_image_classification.md):
+ *   Encoder.forward  R.md:312        Decoder.forward R.md:386-389      SupervisedAutoencoder.forward R.md:429-433
+ *   AE train step    R.md:646-654    AE validation step R.md:673-677   MLP.forward R.md:2565
+ *   MLP train step   R.md:2641-2646  extract_features R.md:2498-2510   final evaluate R.md:3171-3187
+ * Each entry point below names the reference lines it replaces.  The Python shells in
+ * hybrid-autoencoder-mlp-pipeline-for-satellite-image-classification_amd/ bind these with ctypes.
+ *
+ * Conventions: every function returns 0 on success and a negative code on error (message: eae_last_error());
+ * no C++ exception crosses the boundary.  All tensor arguments are raw DEVICE pointers owned by the caller with the
+ * layout stated per argument; `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing
+ * synchronises except eae_destroy / eae_mlp_destroy.  A ctx is bound to the current device and used from one thread.
+ */
+#ifndef EAE_H
+#define EAE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EAE_OK 0
+#define EAE_ERR_ARG (-2)     /* bad shape / null pointer / unsupported configuration */
+#define EAE_ERR_HIP (-3)     /* a HIP runtime call failed */
+#define EAE_ERR_STATE (-4)   /* call order (e.g. backward without forward, ctx not bound) */
+
+const char* eae_last_error(void);
+int eae_version(void);
+
+/* ------------------------------------------------------------------ autoencoder engine ---------------------- */
+typedef struct eae_ctx eae_ctx;
+
+typedef struct eae_config {
+  int latent_dim;    /* Encoder/Decoder/SupervisedAutoencoder(latent_dim)  R.md:288, 362, 417 */
+  int num_classes;   /* SupervisedAutoencoder(num_classes=10)             R.md:417 */
+  int image_h;       /* 64 for EuroSAT; must be a multiple of 64 */
+  int image_w;
+  int max_batch;     /* workspaces are sized for this many images per call */
+} eae_config;
+
+#define EAE_AE_NPARAMS 38   /* model.parameters() order of SupervisedAutoencoder */
+#define EAE_AE_NBN 7        /* BatchNorm2d layers: enc.encoder.{1,4,7,10}, dec.decoder.{2,5,8} */
+
+/* Flat arena layout.  param_off[i] (i < 38) = element offset of the i-th tensor of named_parameters() in the fp32
+ * parameter / gradient / Adam arenas, param_off[38] = arena length (multiple of 4; every tensor 16-byte aligned).
+ * bn_off[2*l] / bn_off[2*l+1] = offsets of running_mean / running_var of BN layer l in the running-stat arena,
+ * bn_off[14] = its length. */
+int eae_ae_layout(const eae_config* cfg, long long* param_off, long long* bn_off);
+
+int eae_create(const eae_config* cfg, eae_ctx** out);
+int eae_destroy(eae_ctx* ctx);
+
+/* Bind the caller-owned arenas (fp32 unless noted).  grads/adam_m/adam_v may be NULL for inference-only use.
+ * bn_nbt: int64[7] num_batches_tracked. */
+int eae_bind(eae_ctx* ctx, float* params, float* grads, float* adam_m, float* adam_v, float* bn_running,
+             long long* bn_nbt);
+/* The host changed parameter values (load_state_dict, optimizer outside the engine): repack before next use. */
+int eae_params_changed(eae_ctx* ctx);
+int eae_set_adam_step(eae_ctx* ctx, long long step);
+long long eae_get_adam_step(eae_ctx* ctx);
+
+typedef struct eae_step_io {
+  const float* x;            /* [B,3,H,W] fp32 NCHW, the loader contract (R.md:643) */
+  const long long* labels;   /* [B] int64 (R.md:644) or NULL */
+  int B;
+  int train;                 /* 1: model.train() semantics (batch statistics, running-stat update); 0: model.eval() */
+  int head;                  /* 1: classifier head + CrossEntropy; 0: encoder+decoder only (MSE) */
+  float alpha;               /* loss = alpha * MSE(x_hat, x) + CE(logits, labels)   R.md:649-651 */
+  float* x_hat;              /* optional [B,3,H,W] fp32 NCHW */
+  float* logits;             /* optional [B,num_classes] fp32 */
+  float* z;                  /* optional [B,latent_dim] fp32 */
+  float* loss_accum;         /* optional float[8]: += loss*B, mse*B, ce*B, B, #correct  (R.md:656-657, 679-681) */
+  float* loss_last;          /* optional float[4]: loss, mse, ce of this call */
+} eae_step_io;
+
+/* x_hat, logits, z = model(x) (R.md:647 / 673), plus the loss terms when io->x target / labels are given. */
+int eae_ae_forward(eae_ctx* ctx, void* stream, const eae_step_io* io);
+/* zero_grad + forward + loss + backward (R.md:646-653): gradients of all 38 tensors land in the grad arena. */
+int eae_ae_grad_step(eae_ctx* ctx, void* stream, const eae_step_io* io);
+/* optimizer.step() of torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) over the bound arenas (R.md:624, 654). */
+int eae_adam_step(eae_ctx* ctx, void* stream, float lr, float weight_decay);
+/* eae_ae_grad_step + eae_adam_step: one iteration of the reference's batch loop (R.md:642-658). */
+int eae_ae_train_step(eae_ctx* ctx, void* stream, const eae_step_io* io, float lr);
+/* Encoder alone in the current mode (extract_features, R.md:2504: z = encoder(imgs)). */
+int eae_encoder_forward(eae_ctx* ctx, void* stream, const float* x, int B, int train, float* z);
+/* Decoder alone (Decoder.forward, R.md:386-389). */
+int eae_decoder_forward(eae_ctx* ctx, void* stream, const float* z, int B, int train, float* x_hat);
+
+/* ------------------------------------------------------------------ per-op entry points ---------------------- */
+/* Building blocks of the fused step, exported for kernel-level parity tests.  Activations are NHWC bf16. */
+typedef struct eae_src {
+  const void* p0;      /* mode 0: tensor; 1: raw pre-BN tensor y; 2: masked gradient g; 3: fp32 tensor */
+  const void* p1;      /* mode 2: raw pre-BN tensor y */
+  const float* coef;   /* mode 1: [4][C] s,t,mean,invstd; mode 2: [3][C] A,B,C */
+  int mode;            /* 0 raw, 1 BN-apply+ReLU on load, 2 BN-backward-apply on load, 3 fp32 */
+} eae_src;
+
+/* kind 0: 3x3 stride-2 pad-1 conv (aten::convolution of nn.Conv2d, R.md:292-304);
+ * kind 1: 3x3 stride-2 pad-1 output_padding-1 transposed conv (nn.ConvTranspose2d, R.md:370-378).
+ * wpack: bf16 [cout][9][cin].  epilogue 0: +bias, raw bf16 out, statistics partials [ntiles][2][cout];
+ * 1: ReLU mask of (yprev, prev_coef) + BN-backward partials; 2: plain store. */
+int eae_op_conv_s2(void* stream, int kind, eae_src src, int cin, int cout, int B, int Hin, int Win, const void* wpack,
+                   const float* bias, void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef);
+int eae_op_conv_s2_ntiles(int kind, int B, int Hin, int Win);
+/* first / last layer kernels: src3_kind 0 = fp32 NCHW [B,3,H,W], 1 = bf16 NHWC4 [B,H,W,4]; out [B,H/2,W/2,32] */
+int eae_op_edge_conv(void* stream, int src3_kind, const void* src3, int B, int H, int W, const void* wpack32x32,
+                     const float* bias, void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef);
+int eae_op_edge_wgrad(void* stream, int src3_kind, const void* src3, int B, int H, int W, eae_src side, float* scratch,
+                      long long scratch_floats, float* dw /*[32][3][3][3]*/);
+int eae_op_deconv4_loss(void* stream, eae_src a3, int B, int Hin, int Win, const void* wjoint, const float* bias,
+                        const float* x, float gscale, float* x_hat, void* g4, float* loss_part /*[ntiles][4]*/);
+/* weight gradient of a 3x3 s2 layer: dw [cs][cb][3][3] fp32 (reference layout) */
+int eae_op_wgrad_s2(void* stream, eae_src small_src, eae_src big_src, int cs, int cb, int B, int Hs, int Ws, float* scratch,
+                    long long scratch_floats, float* dw);
+int eae_op_bn_finalize(void* stream, const float* stat_part, int ntiles, int C, long long count, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, long long* nbt, float momentum,
+                       float eps, float* coef);
+int eae_op_bn_eval_coef(void* stream, int C, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* coef);
+int eae_op_bn_bwd_finalize(void* stream, const float* stat_part, int ntiles, int C, long long count, const float* gamma,
+                           const float* coef_fwd, float* dgamma, float* dbeta, float* coef_bwd);
+/* pack a [A][B][3][3] fp32 weight into bf16 p1 [A][9][B] and p2 [B][9][A] */
+int eae_op_pack3x3(void* stream, const float* w, int A, int B, void* p1, void* p2);
+int eae_op_adam(void* stream, float* p, const float* g, float* m, float* v, long long n, double lr, double beta1,
+                double beta2, double eps, double weight_decay, long long step);
+
+/* ------------------------------------------------------------------ external MLP (R.md:2549-2566) ---------- */
+typedef struct eae_mlp eae_mlp;
+#define EAE_MLP_NPARAMS 10
+int eae_mlp_layout(int input_dim, int num_classes, long long* param_off /*[11]*/, long long* bn_off /*[5]*/);
+int eae_mlp_create(int input_dim, int num_classes, int max_batch, eae_mlp** out);
+int eae_mlp_destroy(eae_mlp* m);
+int eae_mlp_bind(eae_mlp* m, float* params, float* grads, float* adam_m, float* adam_v, float* bn_running,
+                 long long* bn_nbt);
+int eae_mlp_set_adam_step(eae_mlp* m, long long step);
+/* logits = clf(xb) (R.md:2643 train mode / 2663, 3182 eval mode); dropout mask = Philox(seed, step counter) or the
+ * caller-supplied keep-mask [B][128] (fp32 0/1) when drop_mask != NULL. */
+int eae_mlp_forward(eae_mlp* m, void* stream, const float* x, int B, int train, unsigned long long seed,
+                    const float* drop_mask, float* logits);
+/* one iteration of R.md:2641-2649: zero_grad, forward, CE, backward, Adam(lr, weight_decay);
+ * stats: float[8] += loss*B, B, #correct. */
+int eae_mlp_train_step(eae_mlp* m, void* stream, const float* x, const long long* labels, int B, float lr,
+                       float weight_decay, unsigned long long seed, const float* drop_mask, float* logits, float* stats);
+/* forward + CE + accuracy bookkeeping without update (validation / test loops, R.md:2660-2668, 2689-2695) */
+int eae_mlp_eval_step(eae_mlp* m, void* stream, const float* x, const long long* labels, int B, float* logits,
+                      float* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAE_H */

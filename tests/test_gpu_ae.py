@@ -1,0 +1,173 @@
+"""End-to-end parity of the fused autoencoder path (C ABI: eae_ae_forward / eae_ae_grad_step / eae_ae_train_step).
+
+Two references per quantity:
+  (1) the golden vectors produced by the reference's own fp32 classes (tests/golden/*.npz) -- tolerances for the bf16
+      path from SURVEY.md 8c: x_hat <= 3e-2 max-abs and <= 3e-3 mean-abs, logits / z <= 2 % of the tensor's abs-max;
+  (2) the NumPy oracle with bf16 storage emulation (same rounding points as the kernels) -- tight tolerances.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from helpers import ae_state_np, load_state_np
+from oracle import ae_numpy as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(latent=64, sd=None):
+    import eae_amd
+    torch.manual_seed(gu.AE_SEED)
+    m = eae_amd.SupervisedAutoencoder(latent_dim=latent, num_classes=10)
+    load_state_np(m, sd if sd is not None else ae_state_np(latent))
+    return m.to("cuda")
+
+
+def _engine(m, max_batch=64):
+    from eae_amd.engine import engine_for
+    return engine_for(m, max_batch=max_batch)
+
+
+def _cuda(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def _check_fwd(x_hat, logits, z, g, prefix=""):
+    xh = g[prefix + "x_hat"]
+    d = np.abs(x_hat - xh)
+    assert d.max() <= 3e-2 and d.mean() <= 3e-3, (d.max(), d.mean())
+    assert np.abs(logits - g[prefix + "logits"]).max() <= 0.02 * np.abs(g[prefix + "logits"]).max()
+    assert np.abs(z - g[prefix + "z"]).max() <= 0.02 * np.abs(g[prefix + "z"]).max()
+
+
+@pytest.mark.parametrize("b", [2, 8])
+def test_forward_train_and_eval_vs_golden(golden, b):
+    g = golden(f"ae_fwd_bwd_b{b}.npz")
+    m = _model()
+    eng = _engine(m)
+    x = _cuda(g["x"])
+    xh, lg, z = eng.forward(x, train=False)
+    _check_fwd(xh.cpu().numpy(), lg.cpu().numpy(), z.cpu().numpy(), g, "eval_")
+    xh, lg, z = eng.forward(x, labels=_cuda(g["labels"]), train=True, alpha=float(g["alpha"]))
+    torch.cuda.synchronize()
+    _check_fwd(xh.cpu().numpy(), lg.cpu().numpy(), z.cpu().numpy(), g)
+    last = eng.loss_last.cpu().numpy()
+    assert abs(last[0] - g["loss"]) <= 0.02 * abs(g["loss"]), (last, g["loss"])
+    assert abs(last[1] - g["loss_recon"]) <= 0.02 * g["loss_recon"]
+    assert abs(last[2] - g["loss_class"]) <= 0.02 * g["loss_class"]
+    # running statistics after one training-mode forward (BatchNorm momentum update)
+    sd = m.state_dict()
+    for k in g.files:
+        if k.startswith("buf/"):
+            name = k[4:]
+            if name.endswith("num_batches_tracked"):
+                assert int(sd[name]) == int(g[k]), name
+            else:
+                np.testing.assert_allclose(sd[name].cpu().numpy(), g[k], rtol=2e-2, atol=2e-3, err_msg=name)
+
+
+def test_forward_vs_bf16_oracle():
+    p = ae_state_np()
+    x, y = gu.make_images(8, 100)
+    out = O.ae_forward(p, x, train=True, quant="bf16")
+    m = _model()
+    eng = _engine(m)
+    xh, lg, z = eng.forward(_cuda(x), labels=_cuda(y), train=True, alpha=35.0)
+    torch.cuda.synchronize()
+    assert np.abs(z.cpu().numpy() - out["z"]).max() <= 4e-3 * np.abs(out["z"]).max()
+    assert np.abs(lg.cpu().numpy() - out["logits"]).max() <= 4e-3 * np.abs(out["logits"]).max()
+    # sigmoid output: a handful of bf16 rounding flips upstream move single pixels by a few 1e-3
+    d = np.abs(xh.cpu().numpy() - out["x_hat"])
+    assert d.max() <= 1.2e-2 and d.mean() <= 4e-4, (d.max(), d.mean())
+
+
+def test_gradients_vs_golden_and_oracle(golden):
+    import gpu_util as G
+    g = golden("ae_fwd_bwd_b8.npz")
+    p = ae_state_np()
+    x, y = g["x"], g["labels"]
+    alpha = float(g["alpha"])
+    m = _model()
+    eng = _engine(m)
+    eng.grad_step(_cuda(x), _cuda(y), alpha)
+    torch.cuda.synchronize()
+    eng.expose_grads()
+    out = O.ae_forward(p, x, train=True, quant="bf16")
+    gq = O.ae_backward(p, out, x, y, alpha, quant="bf16")
+    report = []
+    bad = []
+    for name, prm in m.named_parameters():
+        got = prm.grad.cpu().numpy()
+        ref32 = g[f"grad/{name}"]
+        if np.abs(ref32).max() < 1e-6:          # bias in front of BatchNorm: identically zero here
+            assert np.abs(got).max() == 0.0, name
+            continue
+        refq = gq[name]
+        r_q, c_q, c_32 = G.relmax(got, refq), G.cosine(got, refq), G.cosine(got, ref32)
+        report.append(f"{name:28s} vs-bf16-oracle relmax {r_q:.3e} cos {c_q:.5f} | vs-fp32-golden cos {c_32:.5f}")
+        if not (c_q > 0.995 and c_32 > 0.97):
+            bad.append(name)
+    print("\n".join(report))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("b", [32, 48, 56])
+def test_big_and_short_batches(golden, b):
+    g = golden(f"ae_fwd_bwd_b{b}.npz")
+    x, y = gu.make_images(b, int(g["seed"]))
+    m = _model()
+    eng = _engine(m)
+    xh, lg, z = eng.forward(_cuda(x), labels=_cuda(y), train=True, alpha=float(g["alpha"]))
+    torch.cuda.synchronize()
+    d = np.abs(xh.cpu().numpy().ravel()[::7] - g["x_hat"])
+    assert d.max() <= 3e-2 and d.mean() <= 3e-3
+    assert np.abs(lg.cpu().numpy() - g["logits"]).max() <= 0.02 * np.abs(g["logits"]).max()
+    assert abs(eng.loss_last.cpu().numpy()[0] - g["loss"]) <= 0.02 * abs(g["loss"])
+
+
+def test_eval_b1_and_latent128(golden):
+    g = golden("ae_eval_b1.npz")
+    m = _model()
+    xh, lg, z = _engine(m).forward(_cuda(g["x"]), train=False)
+    assert np.abs(xh.cpu().numpy() - g["eval_x_hat"]).max() <= 3e-2
+    assert np.abs(lg.cpu().numpy() - g["eval_logits"]).max() <= 0.02 * np.abs(g["eval_logits"]).max()
+    g = golden("ae_latent128_b8.npz")
+    m = _model(128)
+    xh, lg, z = _engine(m).forward(_cuda(g["x"]), train=True)
+    assert np.abs(xh.cpu().numpy() - g["x_hat"]).max() <= 3e-2
+    assert np.abs(z.cpu().numpy() - g["z"]).max() <= 0.02 * np.abs(g["z"]).max()
+
+
+@pytest.mark.parametrize("tag,head", [("joint", True), ("recon", False)])
+def test_adam_trajectory_vs_golden(golden, tag, head):
+    g = golden(f"ae_adam5_{tag}_b8.npz")
+    m = _model()
+    eng = _engine(m)
+    alpha = float(g["alpha"]) if head else 1.0
+    losses = []
+    for step in range(5):
+        x, y = gu.make_images(8, 200 + step)
+        eng.train_step(_cuda(x), _cuda(y), alpha, float(g["lr"]), head=head)
+        losses.append(float(eng.loss_last.cpu().numpy()[0]))
+    # Adam's sign-like first steps at lr=5e-3 make the trajectory chaotic: the NumPy oracle with bf16 storage emulation
+    # itself drifts from the fp32 golden by 0.2 % / 0.2 % / 0.9 % / 5.7 % over steps 2..5 (measured), so the bound
+    # widens with the step index.
+    np.testing.assert_allclose(np.array(losses)[:3], g["losses"][:3], rtol=1e-2)
+    np.testing.assert_allclose(np.array(losses), g["losses"], rtol=0.12)
+    sd = m.state_dict()
+    assert int(sd["enc.encoder.1.num_batches_tracked"]) == 5
+
+
+def test_determinism():
+    x, y = gu.make_images(8, 100)
+    outs = []
+    for _ in range(2):
+        m = _model()
+        eng = _engine(m)
+        for s in range(2):
+            eng.train_step(_cuda(x), _cuda(y), 35.0, 5e-3)
+        torch.cuda.synchronize()
+        outs.append(eng.params.cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[1])
