@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Throughput of the supervised conv-autoencoder train step (BASELINE.json metric) on 1..8 MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one full iteration of the reference's batch loop (R.md:646-654): forward, alpha*MSE + CE, backward, Adam, on a
+device-resident synthetic batch of EuroSAT-shaped 64x64 RGB images (BASELINE.json configs[2]: batch 512 per GPU, joint
+AE + classification head, 64-d latent, bf16 storage / fp32 accumulation).  With N > 1 every rank holds a replica and a
+512-image shard of the global batch; gradients are averaged with one RCCL all-reduce per step (weak scaling).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 512
+ALPHA, LR = 35.0, 5e-3          # the reference's best grid point (R.md:2407)
+# algorithmic work per image (SURVEY.md 8d / BASELINE.md section 2)
+FLOP_PER_IMG_TRAIN = 181.92e6
+BYTES_PER_IMG_BF16 = 1.354e6
+BYTES_PER_STEP_WEIGHTS = 44.7e6
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def make_batch(b, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.rand((b, 3, 64, 64), generator=g, dtype=torch.float32)
+    y = torch.randint(0, 10, (b,), generator=g, dtype=torch.int64)
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU restatement (oracle/ae_torch_cpu.py, same module graph as the reference notebook, fp32, torch CPU ops on
+    all host cores) timed on a bounded sample: B=64 (the notebook's batch size, R.md:246) train steps."""
+    from oracle import ae_torch_cpu as T
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = T.build(latent_dim=64, seed=0)
+    opt = T.make_adam(model, LR)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand((64, 3, 64, 64), generator=g)
+    y = torch.randint(0, 10, (64,), generator=g)
+    for _ in range(3):
+        T.train_step(model, opt, x, y, ALPHA)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        T.train_step(model, opt, x, y, ALPHA)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 200:
+            break
+    return {"value": round(64 * n / el, 1), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of batch 64 (fp32, torch CPU ops, oracle/ae_torch_cpu.py)"}
+
+
+def kernel_roofline(eng, x, y, reps=30):
+    """Per-launch duration of the dominant kernel measured with HIP events on the launch stream, priced against its
+    bounding roofline with ALGORITHMIC bytes / flops (DESIGN.md section 'Roofline accounting')."""
+    from eae_amd import profile_hooks as PH
+    return PH.dominant_kernel_roofline(eng, x, y, reps, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFLOPS)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import eae_amd
+    from eae_amd.engine import engine_for
+    from eae_amd import dp
+
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    torch.manual_seed(0)
+    model = eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=10).to(device)
+    eng = engine_for(model, max_batch=args.batch)
+    trainer = dp.DataParallelTrainer(eng) if dist_on else None
+    if trainer is not None:
+        trainer.broadcast_parameters()
+    x, y = make_batch(args.batch, device, seed=1234 + rank)
+
+    def step():
+        if trainer is None:
+            eng.train_step(x, y, ALPHA, LR)
+        else:
+            trainer.train_step(x, y, ALPHA, LR)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    loss = float(eng.loss_last[0].item())
+    if not np.isfinite(loss):
+        raise SystemExit("non-finite loss in the timed region")
+
+    if rank == 0:
+        total_images = args.batch * world * args.steps
+        value = total_images / el
+        ms = 1e3 * el / args.steps
+        out = {
+            "metric": "EuroSAT 64x64 RGB images/sec (AE+MLP train step)",
+            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: joint conv-AE + classification head train step (fwd, 35*MSE+CE, bwd, Adam), "
+                                   "64x64x3 inputs, 64-d latent, bf16 storage / fp32 accumulate",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(loss, 4)},
+        }
+        # step-level roofline context
+        step_bytes = args.batch * BYTES_PER_IMG_BF16 + BYTES_PER_STEP_WEIGHTS
+        out["step_roofline"] = {"hbm_floor_us": round(step_bytes / (HBM_PEAK_GBS * 1e3), 1),
+                                "mfma_floor_us": round(args.batch * FLOP_PER_IMG_TRAIN / (MFMA_BF16_PEAK_TFLOPS * 1e6), 1),
+                                "frac_of_hbm_floor": round(step_bytes / (HBM_PEAK_GBS * 1e3) / (ms * 1e3 / world * world), 4)}
+        if not args.no_roofline:
+            try:
+                out["roofline"] = kernel_roofline(eng, x, y)
+            except Exception as e:  # the headline number must still be printed
+                out["roofline"] = {"error": str(e)[:200]}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:
+                out["cpu_baseline"] = {"error": str(e)[:200]}
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

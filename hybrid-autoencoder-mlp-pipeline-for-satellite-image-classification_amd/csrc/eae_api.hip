@@ -123,7 +123,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   const int ksplit = (int)(c->K / 128);
   size_t o_fcp = carve((size_t)ksplit * Bm * c->L * 4);
   size_t o_mse = carve((size_t)eae_edge_tiles((int)Bm, c->H, c->W) * 4 * 4);
-  const long long hb = (Bm + 31) / 32;
+  const long long hb = eae_head_blocks((int)Bm);
   c->head_stride = r4(128LL * c->L) + 128 + r4(128LL * c->C) + r4(c->C);
   size_t o_ce = carve(hb * 2 * 4), o_head = carve(hb * c->head_stride * 4), o_loss = carve(64 * 4);
   // ---- pack arena
@@ -180,6 +180,9 @@ extern "C" int eae_bind(eae_ctx* c, float* params, float* grads, float* adam_m, 
   if (!c || !params || !bn_running) return eae_set_error(EAE_ERR_ARG, "bind: ctx, params and bn_running are required");
   c->P = params; c->G = grads; c->M = adam_m; c->V = adam_v; c->bnrun = bn_running; c->nbt = bn_nbt;
   c->packed = false; c->fwd_ready = false;
+  if (grads)
+    for (int k = 0; k < 7; ++k)
+      EAE_HIP(hipMemset(grads + c->poff[PREBN_BIAS[k]], 0, (size_t)(c->poff[PREBN_BIAS[k] + 1] - c->poff[PREBN_BIAS[k]]) * 4));
   return 0;
 }
 extern "C" int eae_params_changed(eae_ctx* c) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->packed = false; c->fwd_ready = false; return 0; }
@@ -314,7 +317,7 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
   if (head) RC(run_head(c, st, B, io->labels, io->logits, want_grad));
   if (io->z) EAE_HIP(hipMemcpyAsync(io->z, c->z, (size_t)B * c->L * 4, hipMemcpyDeviceToDevice, st));
   if (want_loss || want_grad) {
-    const int n_ce = (head && io->labels) ? (B + 31) / 32 : 0;
+    const int n_ce = (head && io->labels) ? eae_head_blocks(B) : 0;
     RC(eae_launch_loss_finalize(st, c->msepart, eae_edge_tiles(B, c->H, c->W), c->cepart, n_ce, io->alpha, numel, B,
                                 want_grad ? c->G + c->poff[33] : nullptr, io->loss_accum, io->loss_last));
   }
@@ -326,7 +329,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io) {
   const bool head = io->head != 0;
   // ---- classifier weight gradients (partials written by the head kernel)
   if (head) {
-    const int nb = (B + 31) / 32;
+    const int nb = eae_head_blocks(B);
     hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((c->head_stride / 4 + 63) / 64)), dim3(256), 0, st, c->headpart, nb,
                        (long)(c->head_stride / 4), c->G + c->poff[34], 1.0f);
     EAE_LAUNCH_CHECK();
@@ -416,9 +419,8 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io) {
   // ---- conv1 weight gradient
   RC(eae_launch_edge_wgrad(st, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, c->wscratch,
                            c->wscratch_floats, c->G + c->poff[0]));
-  // ---- biases in front of a BatchNorm: gradient is identically zero (the reference computes ~1e-9 rounding noise)
-  for (int k = 0; k < 7; ++k)
-    EAE_HIP(hipMemsetAsync(c->G + c->poff[PREBN_BIAS[k]], 0, (size_t)(c->poff[PREBN_BIAS[k] + 1] - c->poff[PREBN_BIAS[k]]) * 4, st));
+  // Biases in front of a BatchNorm have an identically zero gradient (the reference computes ~1e-9 rounding noise);
+  // their slots in the gradient arena are zeroed once in eae_bind and never written.
   return 0;
 }
 

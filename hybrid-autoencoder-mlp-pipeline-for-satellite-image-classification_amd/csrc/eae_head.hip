@@ -1,27 +1,29 @@
 // Classification head of SupervisedAutoencoder (R.md:423-427): Linear(L,128) -> ReLU -> Linear(128,C), fused with
 // CrossEntropyLoss (R.md:623, 650) and the whole backward of the head, in fp32 (9.5 K MAC per image: pure latency).
-// One block handles 32 batch rows: forward, softmax/CE, dlogits, dh, dz and the per-block partial weight gradients,
+// One block handles HR = 8 batch rows: forward, softmax/CE, dlogits, dh, dz and the per-block partial weight gradients,
 // which are laid out exactly like the four head tensors in the parameter arena so one reduce_slices call finishes them.
 #include "eae_internal.h"
 #include "eae_common.cuh"
 #include "eae_head.h"
 
+constexpr int HR = 8;   // batch rows per block
+
 __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   extern __shared__ float sm[];
   const int L = a.L, C = a.C, LS = L + 1;
   float* w1 = sm;                    // [128][L+1]
-  float* zt = w1 + 128 * LS;         // [32][L]
-  float* w2 = zt + 32 * L;           // [C][128]
+  float* zt = w1 + 128 * LS;         // [HR][L]
+  float* w2 = zt + HR * L;           // [C][128]
   float* hp = w2 + C * 128;          // [32][129]  pre-activation
-  float* dh = hp + 32 * 129;         // [32][129]
-  float* lg = dh + 32 * 129;         // [32][16]   logits, then dlogits
-  float* b1 = lg + 32 * 16;          // [128]
+  float* dh = hp + HR * 129;         // [HR][129]
+  float* lg = dh + HR * 129;         // [32][16]   logits, then dlogits
+  float* b1 = lg + HR * 16;          // [128]
   float* b2 = b1 + 128;              // [16]
-  float* rl = b2 + 16;               // [32] per-row loss, [32] per-row correct
+  float* rl = b2 + 16;               // [HR] per-row loss, [HR] per-row correct
   const int tid = threadIdx.x;
-  const int r0 = blockIdx.x * 32;
+  const int r0 = blockIdx.x * HR;
   for (int i = tid; i < 128 * L; i += 256) w1[(i / L) * LS + (i % L)] = a.w1[i];
-  for (int i = tid; i < 32 * L; i += 256) {
+  for (int i = tid; i < HR * L; i += 256) {
     int r = r0 + i / L;
     zt[i] = r < a.B ? a.z[(size_t)r * L + (i % L)] : 0.f;
   }
@@ -31,26 +33,27 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   __syncthreads();
   {   // h_pre[r][j]
     const int j = tid & 127, rh = tid >> 7;
-    float accv[16];
+    constexpr int RH = HR / 2;
+    float accv[RH];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accv[r] = b1[j];
+    for (int r = 0; r < RH; ++r) accv[r] = b1[j];
     for (int k = 0; k < L; ++k) {
       float w = w1[j * LS + k];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accv[r] = fmaf(zt[(rh * 16 + r) * L + k], w, accv[r]);
+      for (int r = 0; r < RH; ++r) accv[r] = fmaf(zt[(rh * RH + r) * L + k], w, accv[r]);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hp[(rh * 16 + r) * 129 + j] = accv[r];
+    for (int r = 0; r < RH; ++r) hp[(rh * RH + r) * 129 + j] = accv[r];
   }
   __syncthreads();
-  for (int i = tid; i < 32 * C; i += 256) {   // logits
+  for (int i = tid; i < HR * C; i += 256) {   // logits
     int r = i / C, c = i % C;
     float s = b2[c];
     for (int j = 0; j < 128; ++j) s = fmaf(fmaxf(hp[r * 129 + j], 0.f), w2[c * 128 + j], s);
     lg[r * 16 + c] = s;
   }
   __syncthreads();
-  if (tid < 32) {   // softmax + CE per row
+  if (tid < HR) {   // softmax + CE per row
     int r = r0 + tid;
     float loss = 0.f, correct = 0.f;
     if (r < a.B) {
@@ -73,18 +76,18 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
     } else {
       for (int c = 0; c < C; ++c) lg[tid * 16 + c] = 0.f;
     }
-    rl[tid] = loss; rl[32 + tid] = correct;
+    rl[tid] = loss; rl[HR + tid] = correct;
   }
   __syncthreads();
   if (tid == 0 && a.loss_part) {
     float s = 0.f, cr = 0.f;
-    for (int r = 0; r < 32; ++r) { s += rl[r]; cr += rl[32 + r]; }
+    for (int r = 0; r < HR; ++r) { s += rl[r]; cr += rl[HR + r]; }
     a.loss_part[blockIdx.x * 2] = s; a.loss_part[blockIdx.x * 2 + 1] = cr;
   }
   if (!a.labels || !a.grad_part) return;
   {   // dh[r][j] = (h_pre > 0) * sum_c dlogits[r][c] * W2[c][j]
     const int j = tid & 127, rh = tid >> 7;
-    for (int r = rh * 16; r < rh * 16 + 16; ++r) {
+    for (int r = rh * (HR / 2); r < (rh + 1) * (HR / 2); ++r) {
       float s = 0.f;
       for (int c = 0; c < C; ++c) s = fmaf(lg[r * 16 + c], w2[c * 128 + j], s);
       dh[r * 129 + j] = hp[r * 129 + j] > 0.f ? s : 0.f;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   }
   __syncthreads();
   // dz_cls[r][k] = sum_j dh[r][j] * W1[j][k]
-  for (int i = tid; i < 32 * L; i += 256) {
+  for (int i = tid; i < HR * L; i += 256) {
     int r = i / L, k = i % L;
     float s = 0.f;
     for (int j = 0; j < 128; ++j) s = fmaf(dh[r * 129 + j], w1[j * LS + k], s);
@@ -103,36 +106,36 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
   for (int i = tid; i < 128 * L; i += 256) {
     int j = i / L, k = i % L;
     float s = 0.f;
-    for (int r = 0; r < 32; ++r) s = fmaf(dh[r * 129 + j], zt[r * L + k], s);
+    for (int r = 0; r < HR; ++r) s = fmaf(dh[r * 129 + j], zt[r * L + k], s);
     gp[i] = s;
   }
   if (tid < 128) {
     float s = 0.f;
-    for (int r = 0; r < 32; ++r) s += dh[r * 129 + tid];
+    for (int r = 0; r < HR; ++r) s += dh[r * 129 + tid];
     gp[128 * L + tid] = s;
   }
   for (int i = tid; i < C * 128; i += 256) {
     int c = i / 128, j = i % 128;
     float s = 0.f;
-    for (int r = 0; r < 32; ++r) s = fmaf(lg[r * 16 + c], fmaxf(hp[r * 129 + j], 0.f), s);
+    for (int r = 0; r < HR; ++r) s = fmaf(lg[r * 16 + c], fmaxf(hp[r * 129 + j], 0.f), s);
     gp[128 * L + 128 + i] = s;
   }
   if (tid < ((C + 3) & ~3)) {
     float s = 0.f;
-    if (tid < C) for (int r = 0; r < 32; ++r) s += lg[r * 16 + tid];
+    if (tid < C) for (int r = 0; r < HR; ++r) s += lg[r * 16 + tid];
     gp[128 * L + 128 + C * 128 + tid] = s;
   }
 }
 
 int eae_launch_head(hipStream_t st, const HeadArgs& a) {
   if (a.L > 128 || a.C > 16 || a.L % 4) return eae_set_error(-2, "head: latent_dim must be <= 128 (multiple of 4), classes <= 16");
-  size_t smem = sizeof(float) * ((size_t)128 * (a.L + 1) + 32 * a.L + a.C * 128 + 2 * 32 * 129 + 32 * 16 + 128 + 16 + 64);
+  size_t smem = sizeof(float) * ((size_t)128 * (a.L + 1) + HR * a.L + a.C * 128 + 2 * HR * 129 + HR * 16 + 128 + 16 + 2 * HR);
   static size_t attr = 0;
   if (smem > attr) {
     EAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = smem;
   }
-  hipLaunchKernelGGL(head_kernel, dim3((a.B + 31) / 32), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(head_kernel, dim3((a.B + HR - 1) / HR), dim3(256), smem, st, a);
   EAE_LAUNCH_CHECK();
   return 0;
 }
@@ -175,3 +178,5 @@ int eae_launch_loss_finalize(hipStream_t st, const float* mse_part, int n_mse, c
   EAE_LAUNCH_CHECK();
   return 0;
 }
+
+int eae_head_blocks(int B) { return (B + HR - 1) / HR; }

@@ -19,7 +19,7 @@
 
 struct WgradArgs {
   SrcDesc small, big;
-  float* part;            // [nslices][CS*CB*9]
+  float* part;            // [nslices][9][CS][CB]
   int B, Hs, Ws;          // small-map spatial size (big map = 2Hs x 2Ws)
   int tiles_per_block, ntiles;
 };
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void wgrad_s2_kernel(WgradArgs a) {
       }
     }
   }
-  // ---- store the partial in reference layout [cs][cb][9]
+  // ---- store the partial as [tap][cs][cb] (16 consecutive cb per lane group -> 64-byte segments); the reduce kernel
+  //      permutes into the reference layout [cs][cb][3][3]
   float* out = a.part + (size_t)blockIdx.x * ((size_t)CS * CB * 9);
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void wgrad_s2_kernel(WgradArgs a) {
       for (int r = 0; r < 4; ++r) {
         int cs = cs0 + (it0 + ii) * 16 + (lane >> 4) * 4 + r;
         int cb = cb0 + jt * 16 + (lane & 15);
-        out[((size_t)cs * CB + cb) * 9 + tap] = acc[tap][ii][r];
+        out[((size_t)tap * CS + cs) * CB + cb] = acc[tap][ii][r];
       }
 }
 
@@ -163,5 +164,31 @@ static __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* 
     for (int k = 1; k < 4; ++k) { r.x += red[k][lx].x; r.y += red[k][lx].y; r.z += red[k][lx].z; r.w += red[k][lx].w; }
     r.x *= scale; r.y *= scale; r.z *= scale; r.w *= scale;
     reinterpret_cast<float4*>(out)[i] = r;
+  }
+}
+
+// out[cs][cb][tap] = sum_s part[s][tap][cs][cb]   (fixed order); thread = 4 consecutive cb of one (tap, cs)
+static __global__ __launch_bounds__(256) void reduce_slices_perm_kernel(const float* __restrict__ part, int nslices, int CS, int CB,
+                                                                        float* __restrict__ out) {
+  __shared__ float4 red[4][64];
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const long n4 = (long)9 * CS * CB / 4;
+  const long i = (long)blockIdx.x * 64 + lx;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4)
+    for (int sidx = ly; sidx < nslices; sidx += 4) {
+      float4 v = reinterpret_cast<const float4*>(part)[(long)sidx * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  red[ly][lx] = s;
+  __syncthreads();
+  if (ly == 0 && i < n4) {
+    float4 r = red[0][lx];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { r.x += red[k][lx].x; r.y += red[k][lx].y; r.z += red[k][lx].z; r.w += red[k][lx].w; }
+    long e = i * 4;
+    int cb = (int)(e % CB); long t2 = e / CB; int cs = (int)(t2 % CS); int tap = (int)(t2 / CS);
+    float* o = out + ((size_t)cs * CB + cb) * 9 + tap;
+    o[0] = r.x; o[9] = r.y; o[18] = r.z; o[27] = r.w;
   }
 }

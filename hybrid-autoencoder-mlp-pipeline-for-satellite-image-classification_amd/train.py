@@ -1,0 +1,258 @@
+"""fit / evaluate entry points restating the notebook's inline loops (there are no such functions in the reference;
+SURVEY.md 8b):  AE grid + fit loop R.md:599-729, extract_features R.md:2498-2510, MLP grid + fit/test loop R.md:2611-2732,
+final evaluate R.md:3171-3187.  Defaults = the notebook's literals.  Losses / accuracies are accumulated on the device
+and read back once per epoch phase instead of the reference's per-step ``loss.item()`` (same sample-weighted means).
+
+The loops drive a small "stepper" interface so the bookkeeping (weighted epoch means, early stopping, best tracking,
+the reference's aliasing quirks, JSON schema) is testable without a GPU; the default steppers call the HIP engine.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import torch
+
+from .modules import SupervisedAutoencoder, MLP
+
+
+# ------------------------------------------------------------------------------------------------ steppers
+class AEStepper:
+    """HIP-engine stepper for SupervisedAutoencoder: train_step / eval_step / read_loss."""
+
+    def __init__(self, model, alpha, lr, head=True, max_batch=None):
+        from .engine import engine_for
+        self.model, self.alpha, self.lr, self.head = model, float(alpha), float(lr), head
+        self.eng = engine_for(model, max_batch=max_batch)
+        self.eng.reset_optimizer()
+        self.device = self.eng.device
+
+    def begin(self):
+        self.eng.reset_loss()
+
+    def train_step(self, imgs, labels):
+        self.eng.train_step(imgs, labels, self.alpha, self.lr, head=self.head)
+
+    def eval_step(self, imgs, labels):
+        self.eng.forward(imgs, labels=labels, train=False, head=self.head, alpha=self.alpha, want=(), accum=True)
+
+    def end(self):
+        loss, _, _, n, _ = self.eng.read_loss()
+        return loss, n
+
+
+class MLPStepper:
+    def __init__(self, clf, lr, weight_decay=1e-4, max_batch=None):
+        from .mlp_engine import mlp_engine_for
+        self.clf, self.lr, self.wd = clf, float(lr), float(weight_decay)
+        self.eng = mlp_engine_for(clf, max_batch=max_batch)
+        self.eng.reset_optimizer()
+        self.device = self.eng.device
+
+    def begin(self):
+        self.eng.reset_stats()
+
+    def train_step(self, xb, yb):
+        self.eng.train_step(xb, yb, self.lr, self.wd)
+
+    def eval_step(self, xb, yb):
+        self.eng.eval_step(xb, yb)
+
+    def end(self):
+        return self.eng.read_stats()      # (mean loss, accuracy, n)
+
+
+def _to(t, device):
+    return t if t.device == device else t.to(device, non_blocking=True)
+
+
+def _first_batch_size(loader, default=64):
+    bs = getattr(loader, "batch_size", None)
+    return int(bs) if bs else default
+
+
+# ------------------------------------------------------------------------------------------------ autoencoder
+def fit_autoencoder(train_loader, val_loader, alpha, lr, latent_dim=64, num_classes=10, num_epochs=80, patience=15,
+                    device="cuda", model=None, stepper=None, head=True, verbose=True, log=print):
+    """One (alpha, lr) configuration of the reference's AE loop (R.md:619-697).
+
+    Returns dict(model, train_curve, val_curve, best_val_loss, epochs).  As in the reference, `model` holds the weights of
+    the LAST epoch run (R.md:705 keeps a live reference, not the best epoch's weights)."""
+    if model is None and stepper is None:
+        model = SupervisedAutoencoder(latent_dim=latent_dim, num_classes=num_classes).to(device)
+    if stepper is None:
+        stepper = AEStepper(model, alpha, lr, head=head,
+                            max_batch=max(_first_batch_size(train_loader), _first_batch_size(val_loader)))
+    dev = getattr(stepper, "device", None)
+    counter, best_val_loss = 0, float("inf")
+    train_curve, val_curve = [], []
+    for epoch in range(num_epochs):
+        if model is not None:
+            model.train()
+        stepper.begin()
+        for imgs, labels in train_loader:
+            if dev is not None:
+                imgs, labels = _to(imgs, dev), _to(labels, dev)
+            stepper.train_step(imgs, labels)
+        train_loss, _ = stepper.end()
+        train_curve.append(train_loss)
+        if model is not None:
+            model.eval()
+        stepper.begin()
+        with torch.no_grad():
+            for imgs, labels in val_loader:
+                if dev is not None:
+                    imgs, labels = _to(imgs, dev), _to(labels, dev)
+                stepper.eval_step(imgs, labels)
+        val_loss, _ = stepper.end()
+        val_curve.append(val_loss)
+        if verbose:
+            log(f"[AE α={alpha} LR={lr}] Epoch {epoch + 1} | TrainLoss={train_loss:.4f} | ValLoss={val_loss:.4f}")
+        if val_loss < best_val_loss:          # strict improvement, R.md:690
+            best_val_loss = val_loss
+            counter = 0
+        else:
+            counter += 1
+            if counter >= patience:
+                if verbose:
+                    log("Early stopping triggered.")
+                break
+    return {"model": model, "train_curve": train_curve, "val_curve": val_curve, "best_val_loss": best_val_loss,
+            "epochs": len(train_curve)}
+
+
+def grid_search_autoencoder(train_loader, val_loader, alpha_values=(20, 25, 30, 35, 40),
+                            lr_values=(1e-4, 2e-4, 5e-4, 1e-3, 2e-3, 5e-3, 1e-2, 5e-2, 1e-1), latent_dim=64, num_epochs=80,
+                            patience=15, out_dir="models_best", device="cuda", verbose=True, log=print, fit_fn=None):
+    """The reference's alpha x lr grid (R.md:599-729): trains every configuration, keeps the global best, writes
+    `out_dir/AE_GLOBAL_BEST.pt` (plain state_dict) and `out_dir/validation_losses.json` (keys "alpha={a}, lr={lr}")."""
+    os.makedirs(out_dir, exist_ok=True)
+    fit_fn = fit_fn or fit_autoencoder
+    results, best = {}, {"loss": float("inf"), "info": None, "state": None, "train": None, "val": None}
+    for alpha in alpha_values:
+        for lr in lr_values:
+            if verbose:
+                log("\n=====================================")
+                log(f"Training AE for α={alpha}, LR={lr}")
+                log("=====================================")
+            r = fit_fn(train_loader, val_loader, alpha, lr, latent_dim=latent_dim, num_epochs=num_epochs, patience=patience,
+                       device=device, verbose=verbose, log=log)
+            results[(alpha, lr)] = r["best_val_loss"]
+            if r["best_val_loss"] < best["loss"]:
+                best.update(loss=r["best_val_loss"], info=(alpha, lr), train=r["train_curve"], val=r["val_curve"],
+                            state=None if r["model"] is None else {k: v.detach().cpu().clone() for k, v in r["model"].state_dict().items()})
+                if verbose:
+                    log("\nNew best AE")
+                    log(f"   α={alpha}, LR={lr}, ValLoss={r['best_val_loss']:.4f}")
+    best_path = os.path.join(out_dir, "AE_GLOBAL_BEST.pt")
+    if best["state"] is not None:
+        torch.save(best["state"], best_path)
+    with open(os.path.join(out_dir, "validation_losses.json"), "w") as f:
+        json.dump({f"alpha={a}, lr={lr}": float(v) for (a, lr), v in results.items()}, f, indent=4)
+    return {"best_alpha": best["info"][0], "best_lr": best["info"][1], "best_val_loss": best["loss"], "best_path": best_path,
+            "results": results, "best_train_curve": best["train"], "best_val_curve": best["val"]}
+
+
+def extract_features(loader, encoder):
+    """Same name and signature as the reference (R.md:2498-2510): eval-mode encoder over a loader -> CPU (X [N,L], y [N])."""
+    X_list, y_list = [], []
+    encoder.eval()
+    dev = next(encoder.parameters()).device
+    with torch.no_grad():
+        for imgs, labels in loader:
+            imgs = imgs.to(dev, non_blocking=True)
+            z = encoder(imgs)
+            X_list.append(z.cpu())
+            y_list.append(labels.cpu())
+    return torch.cat(X_list, dim=0), torch.cat(y_list, dim=0)
+
+
+# ------------------------------------------------------------------------------------------------ MLP
+def fit_mlp(train_dl, val_dl, test_dl, lr, input_dim=64, num_classes=10, num_epochs=30, weight_decay=1e-4, device="cuda",
+            clf=None, stepper=None, alias_best=True, verbose=True, log=print):
+    """One learning rate of the reference's MLP loop (R.md:2619-2697): Adam(lr, weight_decay), CE, accuracy tracking,
+    best-validation snapshot, test accuracy.
+
+    alias_best=True reproduces the reference's `clf.state_dict().copy()` (R.md:2683): a shallow copy that aliases the
+    live tensors, so the "best" state -- and the test accuracy measured after `load_state_dict` -- are those of the
+    final epoch.  alias_best=False snapshots real copies of the best-validation epoch instead."""
+    if clf is None and stepper is None:
+        clf = MLP(input_dim=input_dim, num_classes=num_classes).to(device)
+    if stepper is None:
+        stepper = MLPStepper(clf, lr, weight_decay, max_batch=max(256, _first_batch_size(train_dl)))
+    dev = getattr(stepper, "device", None)
+    curves = {"train_acc": [], "val_acc": [], "train_loss": [], "val_loss": []}
+    best_val_acc, best_state = 0, None
+
+    def run(dl, train):
+        stepper.begin()
+        for xb, yb in dl:
+            if dev is not None:
+                xb, yb = _to(xb, dev), _to(yb, dev)
+            (stepper.train_step if train else stepper.eval_step)(xb, yb)
+        return stepper.end()
+
+    for e in range(num_epochs):
+        if clf is not None:
+            clf.train()
+        tr_loss, tr_acc, _ = run(train_dl, True)
+        if clf is not None:
+            clf.eval()
+        with torch.no_grad():
+            va_loss, va_acc, _ = run(val_dl, False)
+        curves["train_acc"].append(tr_acc); curves["val_acc"].append(va_acc)
+        curves["train_loss"].append(tr_loss); curves["val_loss"].append(va_loss)
+        if verbose:
+            log(f"Epoch {e + 1}/{num_epochs} | TrainAcc={tr_acc:.3f} ValAcc={va_acc:.3f}")
+        if va_acc > best_val_acc:
+            best_val_acc = va_acc
+            if clf is not None:
+                sd = clf.state_dict()
+                best_state = sd.copy() if alias_best else {k: v.detach().clone() for k, v in sd.items()}
+    if clf is not None and best_state is not None:
+        clf.load_state_dict(best_state)
+        clf.eval()
+    with torch.no_grad():
+        _, test_acc, _ = run(test_dl, False)
+    return {"clf": clf, "best_val_acc": best_val_acc, "test_acc": test_acc, "best_state": best_state, **curves}
+
+
+def grid_search_mlp(train_dl, val_dl, test_dl, lr_values=(1e-6, 5e-6, 1e-5, 5e-5, 1e-4, 5e-4, 1e-3, 5e-3, 1e-2, 5e-2, 1e-1),
+                    input_dim=64, num_epochs=30, out_dir="mlp_best", device="cuda", verbose=True, log=print, fit_fn=None):
+    """The reference's MLP learning-rate grid (R.md:2611-2732); saves `out_dir/MLP_GLOBAL_BEST.pt`."""
+    os.makedirs(out_dir, exist_ok=True)
+    fit_fn = fit_fn or fit_mlp
+    best = {"val": 0, "test": 0, "lr": None, "state": None, "curves": None}
+    for lr in lr_values:
+        if verbose:
+            log("\n=====================================")
+            log(f"   Training MLP with LR = {lr}")
+            log("=====================================")
+        r = fit_fn(train_dl, val_dl, test_dl, lr, input_dim=input_dim, num_epochs=num_epochs, device=device, verbose=verbose, log=log)
+        if r["best_val_acc"] > best["val"]:
+            state = r["best_state"]
+            best.update(val=r["best_val_acc"], test=r["test_acc"], lr=lr,
+                        state=None if state is None else {k: v.detach().cpu().clone() for k, v in state.items()},
+                        curves={k: r[k] for k in ("train_acc", "val_acc", "train_loss", "val_loss")})
+    path = os.path.join(out_dir, "MLP_GLOBAL_BEST.pt")
+    if best["state"] is not None:
+        torch.save(best["state"], path)
+    if verbose:
+        log("\n--------------------------------------\nBest MLP\n--------------------------------------")
+        log(f"Best LR             = {best['lr']}")
+        log(f"Best Validation Acc = {best['val']:.4f}")
+        log(f"Test Acc (finale)   = {best['test']:.4f}")
+    return {"best_lr": best["lr"], "best_val_acc": best["val"], "test_acc": best["test"], "best_path": path, "curves": best["curves"]}
+
+
+def evaluate(clf, test_dl):
+    """Final evaluation of the reference (R.md:3171-3187): eval-mode argmax over a loader -> (preds, labels) numpy."""
+    clf.eval()
+    dev = next(clf.parameters()).device
+    all_preds, all_labels = [], []
+    with torch.no_grad():
+        for xb, yb in test_dl:
+            preds = clf(xb.to(dev)).argmax(1).cpu()
+            all_preds.append(preds)
+            all_labels.append(yb.cpu())
+    return torch.cat(all_preds).numpy(), torch.cat(all_labels).numpy()

@@ -1,0 +1,122 @@
+"""Bookkeeping of the fit loops (sample-weighted epoch means are the stepper's job on the device; here: early stopping,
+best tracking, grid JSON schema, the reference's aliasing quirk) with scripted steppers -- no GPU needed.
+Expected values are computed by hand from R.md:656-711 and R.md:2639-2704."""
+import json
+import os
+
+import torch
+
+import eae_amd
+from eae_amd import train as T
+
+
+class ScriptedAE:
+    device = None
+
+    def __init__(self, train_losses, val_losses):
+        self.t, self.v, self.i, self.phase = train_losses, val_losses, 0, None
+        self.calls = []
+
+    def begin(self):
+        self.n = 0
+
+    def train_step(self, x, y):
+        self.phase = "t"; self.n += len(x); self.calls.append(("t", len(x)))
+
+    def eval_step(self, x, y):
+        self.phase = "v"; self.n += len(x); self.calls.append(("v", len(x)))
+
+    def end(self):
+        e = self.i // 2
+        out = (self.t[e] if self.i % 2 == 0 else self.v[e]), self.n
+        self.i += 1
+        return out
+
+
+def _loader(sizes):
+    return [(torch.zeros(b, 1), torch.zeros(b, dtype=torch.int64)) for b in sizes]
+
+
+def test_early_stopping_strict_improvement():
+    # val: improves at epochs 1,2; equal value at epoch 3 is NOT an improvement (strict <, R.md:690); patience 3
+    val = [5.0, 4.0, 4.0, 4.5, 4.2, 3.0, 1.0]
+    st = ScriptedAE([9, 8, 7, 6, 5, 4, 3], val)
+    logs = []
+    r = T.fit_autoencoder(_loader([64, 48]), _loader([64, 56]), alpha=35, lr=1e-3, num_epochs=7, patience=3, stepper=st,
+                          model=None, log=logs.append)
+    assert r["epochs"] == 5                      # epochs 3,4,5 fail to improve -> stop after the 5th
+    assert r["best_val_loss"] == 4.0
+    assert r["val_curve"] == val[:5]
+    assert logs[-1] == "Early stopping triggered."
+    assert logs[0] == "[AE α=35 LR=0.001] Epoch 1 | TrainLoss=9.0000 | ValLoss=5.0000"      # print format R.md:686-687
+    # every batch of both loaders visited once per epoch, train before val
+    assert st.calls[:4] == [("t", 64), ("t", 48), ("v", 64), ("v", 56)]
+
+
+def test_grid_search_bookkeeping(tmp_path):
+    table = {(20, 0.1): 3.0, (20, 0.2): 2.5, (30, 0.1): 2.5, (30, 0.2): 2.7}
+
+    def fake_fit(tr, va, alpha, lr, **kw):
+        return {"model": None, "train_curve": [1.0], "val_curve": [table[(alpha, lr)]], "best_val_loss": table[(alpha, lr)], "epochs": 1}
+
+    out = T.grid_search_autoencoder([], [], alpha_values=(20, 30), lr_values=(0.1, 0.2), out_dir=str(tmp_path), verbose=False, fit_fn=fake_fit)
+    assert (out["best_alpha"], out["best_lr"]) == (20, 0.2)          # first strict minimum wins (R.md:702)
+    js = json.load(open(os.path.join(tmp_path, "validation_losses.json")))
+    assert js == {"alpha=20, lr=0.1": 3.0, "alpha=20, lr=0.2": 2.5, "alpha=30, lr=0.1": 2.5, "alpha=30, lr=0.2": 2.7}
+
+
+class ScriptedMLP:
+    device = None
+
+    def __init__(self, clf, val_acc):
+        self.clf, self.val_acc, self.k, self.epoch = clf, val_acc, 0, 0
+
+    def begin(self):
+        pass
+
+    def train_step(self, x, y):
+        with torch.no_grad():
+            self.clf.net[7].bias += 1.0           # "training" mutates the live weights
+
+    def eval_step(self, x, y):
+        pass
+
+    def end(self):
+        self.k += 1
+        phase = (self.k - 1) % 2                   # 0 = train, 1 = val (the final test call comes last)
+        e = (self.k - 1) // 2
+        if phase == 1 and e < len(self.val_acc):
+            return 0.5, self.val_acc[e], 10
+        return 0.5, 0.25, 10
+
+
+def test_mlp_best_state_aliasing_quirk():
+    val = [0.3, 0.6, 0.5]
+    for alias in (True, False):
+        clf = eae_amd.MLP(64)
+        with torch.no_grad():
+            clf.net[7].bias.zero_()
+        st = ScriptedMLP(clf, val)
+        r = T.fit_mlp(_loader([4]), _loader([4]), _loader([4]), lr=1e-3, num_epochs=3, clf=clf, stepper=st, alias_best=alias,
+                      verbose=False)
+        assert r["best_val_acc"] == 0.6 and r["val_acc"] == val
+        # one train batch per epoch -> bias = epoch count. Best epoch = 2.
+        got = float(clf.net[7].bias[0])
+        if alias:      # reference behaviour (R.md:2683): shallow copy aliases the live tensors -> final-epoch weights
+            assert got == 3.0
+        else:
+            assert got == 2.0
+
+
+def test_evaluate_and_extract_contract_on_cpu_raises():
+    # no CPU fallback: calling the product path without a HIP device must fail loudly
+    import pytest
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    clf = eae_amd.MLP(64)
+    with pytest.raises(RuntimeError):
+        eae_amd.evaluate(clf, _loader([4]))
+    m = eae_amd.SupervisedAutoencoder(64)
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            m(torch.zeros(2, 3, 64, 64))

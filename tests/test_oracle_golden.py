@@ -212,3 +212,22 @@ def test_extract_features_oracle(golden):
         ys.append(y)
     np.testing.assert_allclose(np.concatenate(zs), g["X"], atol=2e-5)
     assert np.array_equal(np.concatenate(ys), g["y"])
+
+
+def test_torch_cpu_port(golden):
+    """oracle/ae_torch_cpu.py (the timed CPU baseline of bench.py) reproduces the reference's outputs and trajectory."""
+    import torch
+    from oracle import ae_torch_cpu as T
+    g = golden("ae_fwd_bwd_b8.npz")
+    p = T.build(state=ae_state_np())
+    xh, lg, z = T.forward(p, torch.from_numpy(g["x"]), True)
+    assert np.abs(xh.detach().numpy() - g["x_hat"]).max() < 1e-5
+    assert np.abs(lg.detach().numpy() - g["logits"]).max() < 5e-5
+    g = golden("ae_adam5_joint_b8.npz")
+    p = T.build(state=ae_state_np())
+    opt = T.make_adam(p, float(g["lr"]))
+    losses = []
+    for step in range(5):
+        x, y = gu.make_images(8, 200 + step)
+        losses.append(T.train_step(p, opt, torch.from_numpy(x), torch.from_numpy(y), float(g["alpha"])))
+    np.testing.assert_allclose(np.array(losses), g["losses"], rtol=1e-4)
