@@ -65,11 +65,11 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"{n} train steps of batch 64 (fp32, torch CPU ops, oracle/ae_torch_cpu.py)"}
 
 
-def kernel_roofline(eng, x, y, reps=30):
-    """Per-launch duration of the dominant kernel measured with HIP events on the launch stream, priced against its
-    bounding roofline with ALGORITHMIC bytes / flops (DESIGN.md section 'Roofline accounting')."""
+def kernel_roofline(eng, step_fn, batch):
+    """Per-launch duration of the dominant kernel measured with HIP events on the launch stream inside real train steps,
+    priced against its bounding roofline with ALGORITHMIC bytes (DESIGN.md section 'Roofline accounting')."""
     from eae_amd import profile_hooks as PH
-    return PH.dominant_kernel_roofline(eng, x, y, reps, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFLOPS)
+    return PH.dominant_kernel_roofline(eng, step_fn, batch, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFLOPS)
 
 
 def main():
@@ -158,10 +158,10 @@ def main():
         step_bytes = args.batch * BYTES_PER_IMG_BF16 + BYTES_PER_STEP_WEIGHTS
         out["step_roofline"] = {"hbm_floor_us": round(step_bytes / (HBM_PEAK_GBS * 1e3), 1),
                                 "mfma_floor_us": round(args.batch * FLOP_PER_IMG_TRAIN / (MFMA_BF16_PEAK_TFLOPS * 1e6), 1),
-                                "frac_of_hbm_floor": round(step_bytes / (HBM_PEAK_GBS * 1e3) / (ms * 1e3 / world * world), 4)}
+                                "frac_of_hbm_floor": round(step_bytes / (HBM_PEAK_GBS * 1e3) / (ms * 1e3), 4)}
         if not args.no_roofline:
             try:
-                out["roofline"] = kernel_roofline(eng, x, y)
+                out["roofline"] = kernel_roofline(eng, step, args.batch)
             except Exception as e:  # the headline number must still be printed
                 out["roofline"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:

@@ -17,7 +17,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libeae.so")
 SOURCES = ["eae_api.hip", "eae_conv_launch.hip", "eae_edge_launch.hip", "eae_wgrad_launch.hip", "eae_fc_launch.hip",
            "eae_misc.hip", "eae_head.hip", "eae_mlp.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"] + os.environ.get("EAE_EXTRA_FLAGS", "").split()
 
 
 def _newest_header():

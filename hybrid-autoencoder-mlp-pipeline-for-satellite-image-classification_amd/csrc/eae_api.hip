@@ -1,7 +1,7 @@
 // C ABI of libeae.so (include/eae.h): context, arena layout, the fused forward / backward / Adam step of the
 // supervised autoencoder, and thin per-op wrappers used by the kernel-level parity tests.
 #include "eae_internal.h"
-#include "eae_conv.cuh"
+#include "eae_igemm.cuh"
 #include "eae_edge.cuh"
 #include "eae_wgrad.cuh"
 #include "eae_fc.cuh"
@@ -68,6 +68,11 @@ struct eae_ctx {
   PackDesc* descs_dev = nullptr;
   int ndesc = 0;
   size_t pk_c1, pk_p1[6], pk_p2[6], pk_d4j, pk_d4k, pk_we1, pk_we2, pk_wd1, pk_wd2, pk_bd;
+  // optional in-situ timing of the dominant kernel (enc.conv2 forward) with HIP events on the launch stream
+  static constexpr int PROF_RING = 64;
+  bool prof_on = false;
+  int prof_n = 0;
+  hipEvent_t prof_ev[2 * PROF_RING] = {};
   long long act_elems(int lvl) const {   // per-image elements of the map after `lvl` stride-2 stages (1..4)
     return (long long)(H >> lvl) * (W >> lvl) * ENC_C[lvl];
   }
@@ -168,9 +173,33 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   return 0;
 }
 
+extern "C" int eae_profile_enable(eae_ctx* c, int on) {
+  if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL");
+  if (on && !c->prof_ev[0])
+    for (int i = 0; i < 2 * eae_ctx::PROF_RING; ++i) EAE_HIP(hipEventCreate(&c->prof_ev[i]));
+  c->prof_on = on != 0;
+  c->prof_n = 0;
+  return 0;
+}
+
+extern "C" int eae_profile_read(eae_ctx* c, double* total_ms, long long* count) {
+  if (!c || !total_ms || !count) return eae_set_error(EAE_ERR_ARG, "profile_read: NULL argument");
+  double tot = 0.0;
+  for (int i = 0; i < c->prof_n; ++i) {
+    float ms = 0.f;
+    EAE_HIP(hipEventSynchronize(c->prof_ev[2 * i + 1]));
+    EAE_HIP(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+    tot += ms;
+  }
+  *total_ms = tot; *count = c->prof_n;
+  c->prof_n = 0;
+  return 0;
+}
+
 extern "C" int eae_destroy(eae_ctx* c) {
   if (!c) return 0;
   hipDeviceSynchronize();
+  if (c->prof_ev[0]) for (int i = 0; i < 2 * eae_ctx::PROF_RING; ++i) hipEventDestroy(c->prof_ev[i]);
   if (c->ws) hipFree(c->ws);
   delete c;
   return 0;
@@ -237,7 +266,10 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
     a.wpack = (const bf16_t*)(c->pack + c->pk_p1[i - 1]); a.bias = c->P + c->poff[4 * i + 1]; a.out = c->y[i];
     a.stat_part = train ? c->stat : nullptr;
     a.B = B; a.Hin = H >> i; a.Win = W >> i;
+    const bool prof = c->prof_on && i == 1 && c->prof_n < eae_ctx::PROF_RING;
+    if (prof) EAE_HIP(hipEventRecord(c->prof_ev[2 * c->prof_n], st));
     RC(eae_launch_conv_s2(a, ENC_C[i], ENC_C[i + 1], SRC_BNRELU, EPI_FWD, st));
+    if (prof) { EAE_HIP(hipEventRecord(c->prof_ev[2 * c->prof_n + 1], st)); c->prof_n++; }
     RC(bn_fwd_finalize(c, st, i, eae_conv_s2_ntiles(0, B, a.Hin, a.Win), (long long)B * (a.Hin / 2) * (a.Win / 2), train));
   }
   FcNtArgs f = FcNtArgs();
@@ -330,7 +362,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io) {
   // ---- classifier weight gradients (partials written by the head kernel)
   if (head) {
     const int nb = eae_head_blocks(B);
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((c->head_stride / 4 + 63) / 64)), dim3(256), 0, st, c->headpart, nb,
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(c->head_stride / 4)), dim3(256), 0, st, c->headpart, nb,
                        (long)(c->head_stride / 4), c->G + c->poff[34], 1.0f);
     EAE_LAUNCH_CHECK();
   } else {
@@ -481,11 +513,18 @@ SrcDesc to_src(const eae_src& s) {
 }
 }  // namespace
 
+#ifdef EAE_STAMPS
+static unsigned long long* g_dbg = nullptr; static int g_dbg_block = 0;
+extern "C" int eae_debug_set(void* p, int block) { g_dbg = (unsigned long long*)p; g_dbg_block = block; return 0; }
+#endif
 extern "C" int eae_op_conv_s2(void* stream, int kind, eae_src src, int cin, int cout, int B, int Hin, int Win, const void* wpack,
                               const float* bias, void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef) {
   ConvArgs a = ConvArgs();
   a.src = to_src(src); a.wpack = (const bf16_t*)wpack; a.bias = bias; a.out = (bf16_t*)out; a.stat_part = stat_part;
   a.yprev = (const bf16_t*)yprev; a.prev_coef = prev_coef; a.B = B; a.Hin = Hin; a.Win = Win;
+#ifdef EAE_STAMPS
+  a.dbg = g_dbg; a.dbg_block = g_dbg_block;
+#endif
   if (kind == 0) return eae_launch_conv_s2(a, cin, cout, src.mode, epilogue, (hipStream_t)stream);
   return eae_launch_deconv_s2(a, cin, cout, src.mode, epilogue, (hipStream_t)stream);
 }

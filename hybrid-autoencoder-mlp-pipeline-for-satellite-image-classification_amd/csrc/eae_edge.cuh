@@ -5,7 +5,7 @@
 // sub-pixel phases jointly (N = 4 phases x 3 channels = 12 of 16 MFMA columns), never by padding in HBM.
 #pragma once
 #include "eae_common.cuh"
-#include "eae_conv.cuh"
+#include "eae_igemm.cuh"
 
 enum { SRC3_NCHW_F32 = 0,     // fp32 planar image (the loader contract)
        SRC3_NHWC4_BF16 = 1 }; // bf16 pixels padded to 4 channels (gradient of the pre-sigmoid output)

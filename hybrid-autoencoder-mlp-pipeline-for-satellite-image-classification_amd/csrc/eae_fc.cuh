@@ -7,7 +7,7 @@
 //                                                                operands via the transposing LDS read)
 #pragma once
 #include "eae_common.cuh"
-#include "eae_conv.cuh"
+#include "eae_igemm.cuh"
 
 enum { FCE_PARTIAL = 0,    // fp32 partial [kslice][M][N]       (split-K)
        FCE_BIAS_BF16 = 1,  // bf16(acc + bias[n]) -> [M][N]

@@ -1,0 +1,292 @@
+// Unified implicit-GEMM kernel for the 3x3 stride-2 convolution family on NHWC bf16 activations (gfx950).
+//
+//   KIND_CONV   : out[n,oy,ox,co] = sum_{ky,kx,ci} T(in)[n,2oy-1+ky,2ox-1+kx,ci] * W[co][ky,kx][ci]
+//                 = forward of nn.Conv2d(3x3,s2,p1) (R.md:292-304) and backward-data of nn.ConvTranspose2d.
+//   KIND_DECONV : out[n,2i+py,2j+px,co] = sum_{taps(py,px),ci} T(in)[n,i+dy,j+dx,ci] * W[co][ky,kx][ci]
+//                 = forward of nn.ConvTranspose2d(3x3,s2,p1,op1) (R.md:370-382) and backward-data of nn.Conv2d; the four
+//                   sub-pixel phases are computed from ONE staged input patch (no zero insertion, no atomics).
+//
+// Structure (one workgroup = 4 waves = P positions x BN output channels):
+//   * the (transformed) input patch of the tile's K-chunk (32 channels) is staged ONCE in LDS -- BatchNorm-apply+ReLU or
+//     BatchNorm-backward-apply happen once per input element while staging -- and the MFMA pixel operand is read
+//     straight out of the patch (the im2col matrix is never materialised);
+//   * the weight operand is NOT staged: each wave reads its own 16-channel fragment rows [cout][tap][32ch] (64 B
+//     contiguous per lane group) directly from L1/L2, all taps of a chunk prefetched into registers while the patch
+//     loads are in flight.  Waves split the output channels (one 16-column n-tile each), so no weight fragment is
+//     fetched twice per workgroup, and the LDS footprint is just the patch -> 2-3 workgroups per CU overlap their
+//     load / MFMA / epilogue phases;
+//   * MFMA = v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the A operand, so an accumulator lane holds 4 consecutive
+//     output channels of one pixel: the epilogue packs them to 8 bytes -> LDS tile -> 16-byte coalesced NHWC stores;
+//   * BatchNorm reductions (forward: sum y, sum y^2; backward: sum g, sum g*xhat) are taken from the values actually
+//     stored, accumulated over all phases, and written as ONE deterministic partial per workgroup (no atomics).
+#pragma once
+#include "eae_common.cuh"
+
+struct ConvArgs {
+  SrcDesc src;
+  const bf16_t* wpack;     // [COUT][9][CIN] bf16 (tap = ky*3+kx)
+  const float* bias;       // [COUT] (EPI_FWD) or nullptr
+  bf16_t* out;             // NHWC bf16
+  float* stat_part;        // [ntiles][2][COUT] or nullptr (no statistics, e.g. eval mode)
+  const bf16_t* yprev;     // EPI_MASK: raw pre-BN tensor at the output positions
+  const float* prev_coef;  // EPI_MASK: [4][COUT] s,t,mean,invstd of that BN
+  int B, Hin, Win;         // input spatial size (conv: out = Hin/2; deconv: out = 2*Hin)
+#ifdef EAE_STAMPS
+  unsigned long long* dbg; // diagnostic build only: s_memtime stamps of workgroup `dbg_block`, wave 0
+  int dbg_block;
+#endif
+};
+
+#ifdef EAE_STAMPS
+#define EAE_STAMP(i) do { if (a.dbg && (int)blockIdx.x == a.dbg_block && blockIdx.y == 0 && threadIdx.x == 0) { \
+    unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); a.dbg[i] = t__; } } while (0)
+#else
+#define EAE_STAMP(i) do {} while (0)
+#endif
+
+enum { KIND_CONV = 0, KIND_DECONV = 1 };
+constexpr int PIX_STRIDE = 40;       // bf16 elements per staged pixel: 32 channels + 8 pad (80 B) -> conflict-free reads
+
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogue helper: rows of a bf16 LDS tile [rows][BN+8] -> global with 16-byte stores, accumulating the per-channel
+// reductions of the values stored.  One instance per thread; thread (r0 = tid / CPR, c = tid % CPR) owns 8 channels.
+// ---------------------------------------------------------------------------------------------------------------
+template <int COUT, int BN, int EPI>
+struct TileEpilogue {
+  static constexpr int TS = BN + 8, CPR = BN / 8, RPP = 256 / CPR;
+  float s1[8], s2[8], ps[8], pt[8], pm[8], pi[8];
+  int c, r0;
+  __device__ __forceinline__ void begin(const ConvArgs& a, int n0) {
+    c = threadIdx.x % CPR; r0 = threadIdx.x / CPR;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    if (EPI == EPI_MASK) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int ch = n0 + c * 8 + j;
+        ps[j] = a.prev_coef[ch]; pt[j] = a.prev_coef[COUT + ch];
+        pm[j] = a.prev_coef[2 * COUT + ch]; pi[j] = a.prev_coef[3 * COUT + ch];
+      }
+    }
+  }
+  // rowmap(row) -> element offset of that output pixel (channel 0) in the NHWC tensor, or -1 if the row is invalid
+  template <class RowMap>
+  __device__ __forceinline__ void rows(const ConvArgs& a, const bf16_t* tile, int n0, int nrows, RowMap rowmap) {
+    for (int row = r0; row < nrows; row += RPP) {
+      long off = rowmap(row);
+      if (off < 0) continue;
+      uint4 v = *reinterpret_cast<const uint4*>(tile + row * TS + c * 8);
+      size_t g = (size_t)off + n0 + c * 8;
+      if (EPI == EPI_FWD) {
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); }
+      } else if (EPI == EPI_MASK) {
+        uint4 yv = *reinterpret_cast<const uint4*>(a.yprev + g);
+        float f[8], y[8];
+        unpack8(v, f);
+        unpack8(yv, y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float act = fmaf(ps[j], y[j], pt[j]);
+          f[j] = act > 0.f ? f[j] : 0.f;
+          float xh = (y[j] - pm[j]) * pi[j];
+          s1[j] += f[j];
+          s2[j] = fmaf(f[j], xh, s2[j]);
+        }
+        v = pack8(f);     // exact: f are bf16 values or zero
+      }
+      *reinterpret_cast<uint4*>(a.out + g) = v;
+    }
+  }
+  // deterministic reduction over the RPP row-groups that share a channel chunk; red = [2][RPP][BN] floats of LDS
+  __device__ __forceinline__ void end(const ConvArgs& a, float* red, int n0, int tile_id) {
+    if (EPI == EPI_PLAIN || a.stat_part == nullptr) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[(0 * RPP + r0) * BN + c * 8 + j] = s1[j];
+      red[(1 * RPP + r0) * BN + c * 8 + j] = s2[j];
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < 2 * BN) {
+      int which = tid / BN, ch = tid % BN;
+      float acc = 0.f;
+      for (int r = 0; r < RPP; ++r) acc += red[(which * RPP + r) * BN + ch];
+      a.stat_part[((size_t)tile_id * 2 + which) * COUT + n0 + ch] = acc;
+    }
+  }
+};
+
+// backwards-compatible free function used by the edge and FC kernels (single-pass tiles)
+template <int COUT, int BN, int EPI, class RowMap>
+__device__ __forceinline__ void tile_epilogue(const ConvArgs& a, bf16_t* tile, float* red, int n0, int tile_id, int nrows,
+                                              RowMap rowmap) {
+  TileEpilogue<COUT, BN, EPI> e;
+  e.begin(a, n0);
+  e.rows(a, tile, n0, nrows, rowmap);
+  e.end(a, red, n0, tile_id);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tile geometry: NI images x TH x TW positions (conv: output pixels; deconv: input positions), P = NI*TH*TW
+// ---------------------------------------------------------------------------------------------------------------
+template <int KIND, int TW, int TH, int NI>
+struct Geo {
+  static constexpr int P = NI * TH * TW;
+  static constexpr int PH = (KIND == KIND_CONV) ? 2 * TH + 1 : TH + 1;
+  static constexpr int PW = (KIND == KIND_CONV) ? 2 * TW + 1 : TW + 1;
+  static constexpr int NPIX = NI * PH * PW;
+  static constexpr int NPH = (KIND == KIND_CONV) ? 1 : 4;          // output phases
+  static constexpr int NOFF = (KIND == KIND_CONV) ? 9 : 4;         // distinct patch offsets
+  // patch pixel of position m for offset 0
+  __device__ static __forceinline__ int pixbase(int m) {
+    int img = m / (TH * TW), ty = (m / TW) % TH, tx = m % TW;
+    return (KIND == KIND_CONV) ? (img * PH + 2 * ty) * PW + 2 * tx : (img * PH + ty) * PW + tx;
+  }
+  // tap (ky,kx) -> patch offset id / phase.  deconv: oy = 2*iy - 1 + ky  =>  ky=1: (py=0, dy=0); ky=2: (py=1, dy=0); ky=0: (py=1, dy=1)
+  __device__ static constexpr int tap_off(int tap) {
+    return (KIND == KIND_CONV) ? tap : ((tap / 3 == 0) ? 2 : 0) + ((tap % 3 == 0) ? 1 : 0);
+  }
+  __device__ static constexpr int tap_phase(int tap) {
+    return (KIND == KIND_CONV) ? 0 : ((tap / 3 != 1) ? 2 : 0) + ((tap % 3 != 1) ? 1 : 0);
+  }
+  __device__ static constexpr int off_delta(int o) {     // patch pixel delta of offset id o
+    return (KIND == KIND_CONV) ? (o / 3) * PW + (o % 3) : (o >> 1) * PW + (o & 1);
+  }
+};
+
+template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
+__global__ __launch_bounds__(256, 2) void igemm_s2_kernel(ConvArgs a) {
+  using G = Geo<KIND, TW, TH, NI>;
+  static_assert(G::P == 64 || G::P == 128, "tile must hold 64 or 128 positions");
+  static_assert(CIN % 32 == 0 && COUT % BN == 0 && (BN == 32 || BN == 64), "shape");
+  constexpr int P = G::P, PH = G::PH, PW = G::PW, NPIX = G::NPIX, NPH = G::NPH;
+  constexpr int WN = BN / 16, WM = 4 / WN;          // waves along N (one 16-col n-tile each) / along M
+  constexpr int MT = (P / 16) / WM;                 // m-tiles (16 positions) per wave
+  constexpr int NPA = (NPIX * 4 + 255) / 256;       // 16-byte patch pieces per thread
+  constexpr int TS = BN + 8;
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  bf16_t* patch = smem;                             // [NPIX][PIX_STRIDE]; reused as the output tile [P][TS] + reduction scratch
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int Hout = (KIND == KIND_CONV) ? a.Hin >> 1 : a.Hin * 2, Wout = (KIND == KIND_CONV) ? a.Win >> 1 : a.Win * 2;
+  const int Hpos = (KIND == KIND_CONV) ? Hout : a.Hin, Wpos = (KIND == KIND_CONV) ? Wout : a.Win;   // position grid
+  const int tiles_x = Wpos / TW, tiles_y = Hpos / TH;
+  int t = blockIdx.x;
+  const int txb = t % tiles_x; t /= tiles_x;
+  const int tyb = t % tiles_y; t /= tiles_y;
+  const int img0 = t * NI;
+  const int n0 = blockIdx.y * BN;
+  const int iy0 = (KIND == KIND_CONV) ? 2 * tyb * TH - 1 : tyb * TH, ix0 = (KIND == KIND_CONV) ? 2 * txb * TW - 1 : txb * TW;
+
+  EAE_STAMP(0);
+  f32x4 acc[NPH][MT];
+#pragma unroll
+  for (int i = 0; i < NPH; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int pixb[MT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) pixb[mi] = G::pixbase((wm * MT + mi) * 16 + (lane & 15));
+  const int kgl = lane >> 4;        // k-group of the lane inside an MFMA (8 channels)
+  const int kgs = tid & 3;          // k-group staged by this thread (256 % 4 == 0 -> fixed per thread)
+  // this lane's weight-fragment row: output channel n0 + wn*16 + (lane&15), 8 input channels kgl*8..
+  const bf16_t* wrow = a.wpack + (size_t)(n0 + wn * 16 + (lane & 15)) * 9 * CIN + kgl * 8;
+
+  for (int chunk = 0; chunk < CIN / 32; ++chunk) {
+    if (chunk) __syncthreads();
+    // ---- weight fragments of all 9 taps of this K-chunk (registers; L1/L2 resident)
+    bf16x8 wf[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) wf[tap] = *reinterpret_cast<const bf16x8*>(wrow + tap * CIN + chunk * 32);
+    // ---- stage the input patch (transform applied once per element)
+    ChanCoef<SRC> cc;
+    cc.load(a.src.coef, CIN, chunk * 32 + kgs * 8);
+    RawPiece<SRC> raw[NPA];
+    bool val[NPA];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      int q = tid + i * 256;
+      int pix = q >> 2;
+      int img = pix / (PH * PW), rem = pix % (PH * PW);
+      int pr = rem / PW, pc = rem % PW;
+      int iy = iy0 + pr, ix = ix0 + pc, n = img0 + img;
+      val[i] = (pix < NPIX) && (n < a.B) && (iy >= 0) && (iy < a.Hin) && (ix >= 0) && (ix < a.Win);
+      size_t off = (((size_t)n * a.Hin + iy) * a.Win + ix) * CIN + chunk * 32 + kgs * 8;
+      load_piece<SRC>(a.src, off, val[i], raw[i]);
+    }
+    EAE_STAMP(1);
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      int q = tid + i * 256;
+      if (q < NPIX * 4)
+        *reinterpret_cast<uint4*>(patch + (q >> 2) * PIX_STRIDE + kgs * 8) = transform_piece<SRC>(raw[i], val[i], cc);
+    }
+    EAE_STAMP(2);
+    __syncthreads();
+    EAE_STAMP(3);
+    // ---- MFMAs: for every distinct patch offset, read the pixel fragments once and feed all taps that use it
+#pragma unroll
+    for (int o = 0; o < G::NOFF; ++o) {
+      bf16x8 pf[MT];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+        pf[mi] = *reinterpret_cast<const bf16x8*>(patch + (pixb[mi] + G::off_delta(o)) * PIX_STRIDE + kgl * 8);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (G::tap_off(tap) != o) continue;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) acc[G::tap_phase(tap)][mi] = mfma16(wf[tap], pf[mi], acc[G::tap_phase(tap)][mi]);
+      }
+    }
+  }
+  // ---- epilogue: per phase, accumulators (lane = pixel, 4 consecutive channels in regs) -> LDS tile -> global
+  EAE_STAMP(4);
+  __syncthreads();
+  EAE_STAMP(5);
+  bf16_t* tile = smem;
+  float* red = reinterpret_cast<float*>(smem + P * TS);
+  TileEpilogue<COUT, BN, EPI> epi;
+  epi.begin(a, n0);
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (EPI == EPI_FWD) bv = *reinterpret_cast<const float4*>(a.bias + n0 + wn * 16 + kgl * 4);
+  const int B = a.B;
+#pragma unroll
+  for (int ph = 0; ph < NPH; ++ph) {
+    if (ph) __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      int row = (wm * MT + mi) * 16 + (lane & 15);
+      uint2 w2;
+      w2.x = pack2(acc[ph][mi][0] + bv.x, acc[ph][mi][1] + bv.y);
+      w2.y = pack2(acc[ph][mi][2] + bv.z, acc[ph][mi][3] + bv.w);
+      *reinterpret_cast<uint2*>(tile + row * TS + wn * 16 + kgl * 4) = w2;
+    }
+    __syncthreads();
+    auto rowmap = [=](int row) -> long {
+      int img = row / (TH * TW), ty = (row / TW) % TH, tx = row % TW;
+      int n = img0 + img;
+      if (n >= B) return -1;
+      int oy = (KIND == KIND_CONV) ? tyb * TH + ty : 2 * (tyb * TH + ty) + (ph >> 1);
+      int ox = (KIND == KIND_CONV) ? txb * TW + tx : 2 * (txb * TW + tx) + (ph & 1);
+      return (((long)n * Hout + oy) * Wout + ox) * COUT;
+    };
+    epi.rows(a, tile, n0, P, rowmap);
+  }
+  EAE_STAMP(6);
+  epi.end(a, red, n0, blockIdx.x);
+  EAE_STAMP(7);
+}
+
+template <int KIND, int BN, int TW, int TH, int NI>
+constexpr size_t igemm_smem() {
+  using G = Geo<KIND, TW, TH, NI>;
+  constexpr size_t patch = (size_t)G::NPIX * PIX_STRIDE * 2;
+  constexpr size_t tile = (size_t)G::P * (BN + 8) * 2 + (size_t)2 * (256 / (BN / 8)) * BN * 4;
+  return patch > tile ? patch : tile;
+}

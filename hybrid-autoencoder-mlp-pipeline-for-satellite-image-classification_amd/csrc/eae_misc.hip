@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackDesc* __restric
 }
 
 int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base) {
-  hipLaunchKernelGGL(pack_all_kernel, dim3(32, ndesc), dim3(256), 0, st, descs_dev, params, (uint8_t*)pack_base);
+  hipLaunchKernelGGL(pack_all_kernel, dim3(128, ndesc), dim3(256), 0, st, descs_dev, params, (uint8_t*)pack_base);
   EAE_LAUNCH_CHECK();
   return 0;
 }

@@ -15,7 +15,7 @@
 // the reference layout, partials are summed in a fixed order by reduce_slices_kernel (deterministic, no atomics).
 #pragma once
 #include "eae_common.cuh"
-#include "eae_conv.cuh"
+#include "eae_igemm.cuh"
 
 struct WgradArgs {
   SrcDesc small, big;
@@ -144,15 +144,16 @@ constexpr size_t wgrad_smem() {
   return (size_t)(NPIX * PIX_STRIDE + 128 * S_STRIDE) * 2;
 }
 
-// out[i] = sum_s part[s][i]   (fixed order).  block (64,4): 64 float4 lanes x 4 slice lanes.
-static __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ part, int nslices, long n4,
-                                                             float* __restrict__ out, float scale) {
-  __shared__ float4 red[4][64];
-  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + lx;
+// Deterministic slice reductions: block = 16 float4 lanes x 16 slice lanes; every thread sums its slices in order, then
+// the 16 slice lanes are combined in a fixed order through LDS.
+template <class Store>
+__device__ __forceinline__ void reduce_slices_body(const float* __restrict__ part, int nslices, long n4, Store store) {
+  __shared__ float4 red[16][16];
+  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + lx;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n4)
-    for (int sidx = ly; sidx < nslices; sidx += 4) {
+    for (int sidx = ly; sidx < nslices; sidx += 16) {
       float4 v = reinterpret_cast<const float4*>(part)[(long)sidx * n4 + i];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -161,34 +162,29 @@ static __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* 
   if (ly == 0 && i < n4) {
     float4 r = red[0][lx];
 #pragma unroll
-    for (int k = 1; k < 4; ++k) { r.x += red[k][lx].x; r.y += red[k][lx].y; r.z += red[k][lx].z; r.w += red[k][lx].w; }
-    r.x *= scale; r.y *= scale; r.z *= scale; r.w *= scale;
-    reinterpret_cast<float4*>(out)[i] = r;
+    for (int k = 1; k < 16; ++k) { r.x += red[k][lx].x; r.y += red[k][lx].y; r.z += red[k][lx].z; r.w += red[k][lx].w; }
+    store(i, r);
   }
 }
 
-// out[cs][cb][tap] = sum_s part[s][tap][cs][cb]   (fixed order); thread = 4 consecutive cb of one (tap, cs)
+// out[i] = sum_s part[s][i]
+static __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ part, int nslices, long n4,
+                                                                   float* __restrict__ out, float scale) {
+  reduce_slices_body(part, nslices, n4, [=](long i, float4 r) {
+    r.x *= scale; r.y *= scale; r.z *= scale; r.w *= scale;
+    reinterpret_cast<float4*>(out)[i] = r;
+  });
+}
+
+// out[cs][cb][tap] = sum_s part[s][tap][cs][cb]; thread = 4 consecutive cb of one (tap, cs)
 static __global__ __launch_bounds__(256) void reduce_slices_perm_kernel(const float* __restrict__ part, int nslices, int CS, int CB,
                                                                         float* __restrict__ out) {
-  __shared__ float4 red[4][64];
-  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-  const long n4 = (long)9 * CS * CB / 4;
-  const long i = (long)blockIdx.x * 64 + lx;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i < n4)
-    for (int sidx = ly; sidx < nslices; sidx += 4) {
-      float4 v = reinterpret_cast<const float4*>(part)[(long)sidx * n4 + i];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-  red[ly][lx] = s;
-  __syncthreads();
-  if (ly == 0 && i < n4) {
-    float4 r = red[0][lx];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) { r.x += red[k][lx].x; r.y += red[k][lx].y; r.z += red[k][lx].z; r.w += red[k][lx].w; }
+  reduce_slices_body(part, nslices, (long)9 * CS * CB / 4, [=](long i, float4 r) {
     long e = i * 4;
     int cb = (int)(e % CB); long t2 = e / CB; int cs = (int)(t2 % CS); int tap = (int)(t2 / CS);
     float* o = out + ((size_t)cs * CB + cb) * 9 + tap;
     o[0] = r.x; o[9] = r.y; o[18] = r.z; o[27] = r.w;
-  }
+  });
 }
+
+static inline unsigned reduce_slices_grid(long n4) { return (unsigned)((n4 + 15) / 16); }

@@ -26,7 +26,7 @@ int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_fl
   }
   hipLaunchKernelGGL(kern, dim3(slices, nblk), dim3(256), smem, st, a);
   EAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_slices_perm_kernel, dim3((unsigned)((sz / 4 + 63) / 64)), dim3(256), 0, st, scratch, slices, CS, CB, dw);
+  hipLaunchKernelGGL(reduce_slices_perm_kernel, dim3(reduce_slices_grid(sz / 4)), dim3(256), 0, st, scratch, slices, CS, CB, dw);
   EAE_LAUNCH_CHECK();
   return 0;
 }

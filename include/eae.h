@@ -87,6 +87,12 @@ int eae_encoder_forward(eae_ctx* ctx, void* stream, const float* x, int B, int t
 /* Decoder alone (Decoder.forward, R.md:386-389). */
 int eae_decoder_forward(eae_ctx* ctx, void* stream, const float* z, int B, int train, float* x_hat);
 
+/* In-situ timing of the dominant kernel (enc.conv2 forward, conv_s2_kernel<32,64,...>) inside real train steps:
+ * HIP events are recorded on the launch stream around that launch for up to 64 steps; eae_profile_read synchronises them
+ * and returns the summed kernel time and the number of launches measured (bench.py's `roofline` object). */
+int eae_profile_enable(eae_ctx* ctx, int on);
+int eae_profile_read(eae_ctx* ctx, double* total_ms, long long* count);
+
 /* ------------------------------------------------------------------ per-op entry points ---------------------- */
 /* Building blocks of the fused step, exported for kernel-level parity tests.  Activations are NHWC bf16. */
 typedef struct eae_src {

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase s_memtime stamps of one workgroup of the igemm kernel (needs a -DEAE_STAMPS build:
+   EAE_EXTRA_FLAGS=-DEAE_STAMPS python <pkg>/build.py --force)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import gpu_util as G  # noqa: E402
+from eae_amd import _lib  # noqa: E402
+from eae_amd._lib import check  # noqa: E402
+
+lib = _lib.load()
+raw = C.CDLL(_lib.LIB_PATH)
+B = 512
+dev = torch.device("cuda:0")
+dbg = torch.zeros(16, dtype=torch.int64, device=dev)
+names = ["loads issued+coef", "transform+LDSwrite", "barrier", "MFMA(last chunk)", "barrier", "tile+rows(all ph)", "stats reduce"]
+for (kind, ci, co, hin) in ((0, 32, 64, 32), (0, 64, 128, 16), (0, 128, 256, 8), (1, 128, 64, 8), (1, 64, 32, 16)):
+    x = (torch.randn((B, hin, hin, ci), device=dev) * 0.5).to(torch.bfloat16)
+    ho = hin // 2 if kind == 0 else hin * 2
+    out = torch.empty((B, ho, ho, co), device=dev, dtype=torch.bfloat16)
+    w = (torch.randn((co, 9, ci), device=dev) * 0.1).to(torch.bfloat16); bias = torch.randn(co, device=dev)
+    nt = lib.eae_op_conv_s2_ntiles(kind, B, hin, hin)
+    part = torch.zeros((nt, 2, co), device=dev)
+    cf = torch.randn((4, ci), device=dev)
+    for blk in (0, nt - 1):
+        raw.eae_debug_set(C.c_void_p(dbg.data_ptr()), blk)
+        for _ in range(3):
+            check(lib.eae_op_conv_s2(G.stream(), kind, G.src(1, x, None, cf), ci, co, B, hin, hin, G.ptr(w), G.ptr(bias), G.ptr(out), G.ptr(part), 0, None, None))
+        torch.cuda.synchronize()
+        t = dbg.cpu().tolist()
+        d = [t[i + 1] - t[i] for i in range(7)]
+        print(f"kind{kind} {ci}->{co} in{hin} blk {blk}: total {t[7]-t[0]} | " + " | ".join(f"{n}: {v}" for n, v in zip(names, d)))
