@@ -45,51 +45,82 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return v;
 }
 
-// Per-thread coefficients of 8 consecutive channels for a source transform.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// one dword = 2 bf16 <-> 2 fp32 (register pair, so that the arithmetic becomes v_pk_fma_f32)
+__device__ __forceinline__ f32x2 up2(uint32_t w) { return (f32x2){__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+__device__ __forceinline__ uint32_t pk2(f32x2 v) {      // v_cvt_pk_bf16_f32 (round-to-nearest-even)
+  bf16x2 r = __builtin_convertvector(v, bf16x2);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t relu2(uint32_t p) { // ReLU on two packed bf16: v_pk_max_i16 with 0 (negative <=> sign bit)
+  s16x2 v = __builtin_bit_cast(s16x2, p);
+  s16x2 z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v, z));
+}
+
+// Per-thread coefficients of 8 consecutive channels for a source transform (as 4 fp32 pairs).
 template <int MODE> struct ChanCoef {
-  float a[8], b[8], c[8];
+  f32x2 a[4], b[4], c[4];
   __device__ __forceinline__ void load(const float* coef, int C, int ch0) {
-    if (MODE == SRC_BNRELU) {
+    if (MODE == SRC_BNRELU || MODE == SRC_BNBWD) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { a[j] = coef[ch0 + j]; b[j] = coef[C + ch0 + j]; }
-    } else if (MODE == SRC_BNBWD) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { a[j] = coef[ch0 + j]; b[j] = coef[C + ch0 + j]; c[j] = coef[2 * C + ch0 + j]; }
+      for (int j = 0; j < 4; ++j) {
+        a[j] = *reinterpret_cast<const f32x2*>(coef + ch0 + 2 * j);
+        b[j] = *reinterpret_cast<const f32x2*>(coef + C + ch0 + 2 * j);
+        if (MODE == SRC_BNBWD) c[j] = *reinterpret_cast<const f32x2*>(coef + 2 * C + ch0 + 2 * j);
+      }
     }
   }
 };
 
-// Raw 16-byte loads of one 8-channel piece (second tensor only for BNBWD).
-template <int MODE> struct RawPiece { uint4 v0, v1; };
+// Buffer resources (V#) of a source: loads through them are bounds-checked by the hardware (out-of-range -> 0), so the
+// zero padding of a patch needs no exec-mask branch: an invalid piece just uses the out-of-range offset OOB_OFF.
+constexpr uint32_t OOB_OFF = 0x7fffff00u;
+struct SrcRsrc {
+  __amdgpu_buffer_rsrc_t r0, r1;
+  template <int MODE> __device__ __forceinline__ void init(const SrcDesc& s) {
+    r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(s.p0), 0, 0x7fffff00, 0x00020000);
+    if (MODE == SRC_BNBWD) r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(s.p1), 0, 0x7fffff00, 0x00020000);
+  }
+};
 
+// Raw 16-byte loads of one 8-channel piece (second tensor only for BNBWD).
+template <int MODE> struct RawPiece { u32x4 v0, v1; };
+
+// byte_off = byte offset of the piece inside the tensor, or OOB_OFF for a piece outside the image
+template <int MODE>
+__device__ __forceinline__ void load_piece_b(const SrcRsrc& rs, uint32_t byte_off, RawPiece<MODE>& r) {
+  r.v0 = __builtin_amdgcn_raw_buffer_load_b128(rs.r0, byte_off, 0, 0);
+  if (MODE == SRC_BNBWD) r.v1 = __builtin_amdgcn_raw_buffer_load_b128(rs.r1, byte_off, 0, 0);
+}
+
+// compatibility form (element offset + validity flag)
 template <int MODE>
 __device__ __forceinline__ void load_piece(const SrcDesc& s, size_t off, bool valid, RawPiece<MODE>& r) {
-  r.v0 = make_uint4(0, 0, 0, 0);
-  r.v1 = make_uint4(0, 0, 0, 0);
-  if (valid) {
-    r.v0 = *reinterpret_cast<const uint4*>(s.p0 + off);
-    if (MODE == SRC_BNBWD) r.v1 = *reinterpret_cast<const uint4*>(s.p1 + off);
-  }
+  SrcRsrc rs;
+  rs.init<MODE>(s);
+  load_piece_b<MODE>(rs, valid ? (uint32_t)(off * 2) : OOB_OFF, r);
 }
 
 // Apply the source transform to a raw piece; out-of-image pieces are exact zeros (zero padding applies to the
-// transformed activation, not to the stored tensor).
+// transformed activation, not to the stored tensor).  20 VALU instructions per 8 elements for BN-apply+ReLU.
 template <int MODE>
 __device__ __forceinline__ uint4 transform_piece(const RawPiece<MODE>& r, bool valid, const ChanCoef<MODE>& cc) {
-  if (MODE == SRC_RAW) return r.v0;
-  if (!valid) return make_uint4(0, 0, 0, 0);
-  float x[8], o[8];
-  unpack8(r.v0, x);
-  if (MODE == SRC_BNRELU) {
+  uint4 o;
+  if (MODE == SRC_RAW) { o.x = r.v0[0]; o.y = r.v0[1]; o.z = r.v0[2]; o.w = r.v0[3]; return o; }
+  uint32_t w[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = fmaxf(fmaf(cc.a[j], x[j], cc.b[j]), 0.0f);
-  } else {
-    float y[8];
-    unpack8(r.v1, y);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = fmaf(cc.a[j], x[j], fmaf(cc.b[j], y[j], cc.c[j]));
+  for (int j = 0; j < 4; ++j) {
+    if (MODE == SRC_BNRELU) w[j] = relu2(pk2(up2(r.v0[j]) * cc.a[j] + cc.b[j]));
+    else w[j] = pk2(up2(r.v0[j]) * cc.a[j] + (up2(r.v1[j]) * cc.b[j] + cc.c[j]));
   }
-  return pack8(o);
+  const uint32_t m = valid ? 0xffffffffu : 0u;
+  o.x = w[0] & m; o.y = w[1] & m; o.z = w[2] & m; o.w = w[3] & m;
+  return o;
 }
 
 __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {

@@ -51,21 +51,24 @@ constexpr int PIX_STRIDE = 40;       // bf16 elements per staged pixel: 32 chann
 // Epilogue helper: rows of a bf16 LDS tile [rows][BN+8] -> global with 16-byte stores, accumulating the per-channel
 // reductions of the values stored.  One instance per thread; thread (r0 = tid / CPR, c = tid % CPR) owns 8 channels.
 // ---------------------------------------------------------------------------------------------------------------
-template <int COUT, int BN, int EPI>
+template <int COUT, int BN, int EPI, bool VALU_STATS = true>
 struct TileEpilogue {
   static constexpr int TS = BN + 8, CPR = BN / 8, RPP = 256 / CPR;
-  float s1[8], s2[8], ps[8], pt[8], pm[8], pi[8];
+  f32x2 s1[4], s2[4], ps[4], pt[4], pmi[4], pi[4];
   int c, r0;
   __device__ __forceinline__ void begin(const ConvArgs& a, int n0) {
     c = threadIdx.x % CPR; r0 = threadIdx.x / CPR;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (int j = 0; j < 4; ++j) { s1[j] = (f32x2){0.f, 0.f}; s2[j] = (f32x2){0.f, 0.f}; }
     if (EPI == EPI_MASK) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        int ch = n0 + c * 8 + j;
-        ps[j] = a.prev_coef[ch]; pt[j] = a.prev_coef[COUT + ch];
-        pm[j] = a.prev_coef[2 * COUT + ch]; pi[j] = a.prev_coef[3 * COUT + ch];
+      for (int j = 0; j < 4; ++j) {
+        int ch = n0 + c * 8 + 2 * j;
+        ps[j] = *reinterpret_cast<const f32x2*>(a.prev_coef + ch);
+        pt[j] = *reinterpret_cast<const f32x2*>(a.prev_coef + COUT + ch);
+        f32x2 m = *reinterpret_cast<const f32x2*>(a.prev_coef + 2 * COUT + ch);
+        pi[j] = *reinterpret_cast<const f32x2*>(a.prev_coef + 3 * COUT + ch);
+        pmi[j] = -m * pi[j];                      // xhat = y*invstd - mean*invstd
       }
     }
   }
@@ -77,37 +80,36 @@ struct TileEpilogue {
       if (off < 0) continue;
       uint4 v = *reinterpret_cast<const uint4*>(tile + row * TS + c * 8);
       size_t g = (size_t)off + n0 + c * 8;
-      if (EPI == EPI_FWD) {
-        float f[8];
-        unpack8(v, f);
+      if (EPI == EPI_FWD && VALU_STATS) {
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s1[j] += f[j]; s2[j] = fmaf(f[j], f[j], s2[j]); }
+        for (int j = 0; j < 4; ++j) { f32x2 f = up2(w[j]); s1[j] += f; s2[j] += f * f; }
       } else if (EPI == EPI_MASK) {
         uint4 yv = *reinterpret_cast<const uint4*>(a.yprev + g);
-        float f[8], y[8];
-        unpack8(v, f);
-        unpack8(yv, y);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float act = fmaf(ps[j], y[j], pt[j]);
-          f[j] = act > 0.f ? f[j] : 0.f;
-          float xh = (y[j] - pm[j]) * pi[j];
-          s1[j] += f[j];
-          s2[j] = fmaf(f[j], xh, s2[j]);
+        for (int j = 0; j < 4; ++j) {
+          f32x2 y = up2(yw[j]);
+          f32x2 act = y * ps[j] + pt[j];
+          uint32_t m = (act.x > 0.f ? 0x0000ffffu : 0u) | (act.y > 0.f ? 0xffff0000u : 0u);
+          w[j] &= m;                               // exact: masked values are bf16 values or zero
+          f32x2 f = up2(w[j]);
+          s1[j] += f;
+          s2[j] += f * (y * pi[j] + pmi[j]);
         }
-        v = pack8(f);     // exact: f are bf16 values or zero
+        v = make_uint4(w[0], w[1], w[2], w[3]);
       }
       *reinterpret_cast<uint4*>(a.out + g) = v;
     }
   }
   // deterministic reduction over the RPP row-groups that share a channel chunk; red = [2][RPP][BN] floats of LDS
   __device__ __forceinline__ void end(const ConvArgs& a, float* red, int n0, int tile_id) {
-    if (EPI == EPI_PLAIN || a.stat_part == nullptr) return;
+    if (EPI == EPI_PLAIN || a.stat_part == nullptr || (EPI == EPI_FWD && !VALU_STATS)) return;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      red[(0 * RPP + r0) * BN + c * 8 + j] = s1[j];
-      red[(1 * RPP + r0) * BN + c * 8 + j] = s2[j];
+    for (int j = 0; j < 4; ++j) {
+      *reinterpret_cast<f32x2*>(red + (0 * RPP + r0) * BN + c * 8 + 2 * j) = s1[j];
+      *reinterpret_cast<f32x2*>(red + (1 * RPP + r0) * BN + c * 8 + 2 * j) = s2[j];
     }
     __syncthreads();
     const int tid = threadIdx.x;
@@ -197,6 +199,8 @@ __global__ __launch_bounds__(256, 2) void igemm_s2_kernel(ConvArgs a) {
   const int kgs = tid & 3;          // k-group staged by this thread (256 % 4 == 0 -> fixed per thread)
   // this lane's weight-fragment row: output channel n0 + wn*16 + (lane&15), 8 input channels kgl*8..
   const bf16_t* wrow = a.wpack + (size_t)(n0 + wn * 16 + (lane & 15)) * 9 * CIN + kgl * 8;
+  SrcRsrc rs;
+  rs.init<SRC>(a.src);
 
   for (int chunk = 0; chunk < CIN / 32; ++chunk) {
     if (chunk) __syncthreads();
@@ -204,21 +208,28 @@ __global__ __launch_bounds__(256, 2) void igemm_s2_kernel(ConvArgs a) {
     bf16x8 wf[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) wf[tap] = *reinterpret_cast<const bf16x8*>(wrow + tap * CIN + chunk * 32);
-    // ---- stage the input patch (transform applied once per element)
+    // ---- stage the input patch (transform applied once per element).  Piece q = tid + 256*i covers patch pixel q/4,
+    //      channels kgs*8..; consecutive i advance the pixel by 64 -> (img, row, col) are updated incrementally, the
+    //      byte offset is 32-bit and out-of-image pieces use the hardware-checked out-of-range offset (no branches).
     ChanCoef<SRC> cc;
     cc.load(a.src.coef, CIN, chunk * 32 + kgs * 8);
     RawPiece<SRC> raw[NPA];
     bool val[NPA];
-#pragma unroll
-    for (int i = 0; i < NPA; ++i) {
-      int q = tid + i * 256;
-      int pix = q >> 2;
+    {
+      constexpr int DR = (64 / PW) % PH, DC = 64 % PW, DI = 64 / (PH * PW);
+      int pix = tid >> 2;
       int img = pix / (PH * PW), rem = pix % (PH * PW);
       int pr = rem / PW, pc = rem % PW;
-      int iy = iy0 + pr, ix = ix0 + pc, n = img0 + img;
-      val[i] = (pix < NPIX) && (n < a.B) && (iy >= 0) && (iy < a.Hin) && (ix >= 0) && (ix < a.Win);
-      size_t off = (((size_t)n * a.Hin + iy) * a.Win + ix) * CIN + chunk * 32 + kgs * 8;
-      load_piece<SRC>(a.src, off, val[i], raw[i]);
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) {
+        int iy = iy0 + pr, ix = ix0 + pc, n = img0 + img;
+        val[i] = (tid + i * 256 < NPIX * 4) && (n < a.B) && ((unsigned)iy < (unsigned)a.Hin) && ((unsigned)ix < (unsigned)a.Win);
+        uint32_t boff = ((uint32_t)((n * a.Hin + iy) * a.Win + ix) * CIN + chunk * 32 + kgs * 8) * 2u;
+        load_piece_b<SRC>(rs, val[i] ? boff : OOB_OFF, raw[i]);
+        pc += DC; pr += DR; img += DI;
+        if (pc >= PW) { pc -= PW; pr += 1; }
+        if (pr >= PH) { pr -= PH; img += 1; }
+      }
     }
     EAE_STAMP(1);
 #pragma unroll
@@ -251,11 +262,21 @@ __global__ __launch_bounds__(256, 2) void igemm_s2_kernel(ConvArgs a) {
   EAE_STAMP(5);
   bf16_t* tile = smem;
   float* red = reinterpret_cast<float*>(smem + P * TS);
-  TileEpilogue<COUT, BN, EPI> epi;
+  TileEpilogue<COUT, BN, EPI, false> epi;
   epi.begin(a, n0);
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (EPI == EPI_FWD) bv = *reinterpret_cast<const float4*>(a.bias + n0 + wn * 16 + kgl * 4);
   const int B = a.B;
+  // BatchNorm batch statistics of the forward epilogue run on the matrix cores: with Y = the stored bf16 tile [P][16],
+  //   sum_p Y[p][j]   = (ones^T . Y)[.][j]         (any row of an MFMA with an all-ones A operand)
+  //   sum_p Y[p][j]^2 = diag(Y^T . Y)[j]           (A and B are the same transposed-read fragment)
+  // wave w < BN/16 owns the 16 channels of n-tile w and sweeps all P rows of every phase.
+  const bool do_stats = (EPI == EPI_FWD) && a.stat_part != nullptr && wave < BN / 16;
+  f32x4 st1 = (f32x4){0.f, 0.f, 0.f, 0.f}, st2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+  const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph) {
     if (ph) __syncthreads();
@@ -263,11 +284,21 @@ __global__ __launch_bounds__(256, 2) void igemm_s2_kernel(ConvArgs a) {
     for (int mi = 0; mi < MT; ++mi) {
       int row = (wm * MT + mi) * 16 + (lane & 15);
       uint2 w2;
-      w2.x = pack2(acc[ph][mi][0] + bv.x, acc[ph][mi][1] + bv.y);
-      w2.y = pack2(acc[ph][mi][2] + bv.z, acc[ph][mi][3] + bv.w);
+      w2.x = pk2((f32x2){acc[ph][mi][0] + bv.x, acc[ph][mi][1] + bv.y});
+      w2.y = pk2((f32x2){acc[ph][mi][2] + bv.z, acc[ph][mi][3] + bv.w});
+      if (NI > 1 && img0 + row / (TH * TW) >= B) w2 = make_uint2(0, 0);   // images past the batch must not enter the statistics
       *reinterpret_cast<uint2*>(tile + row * TS + wn * 16 + kgl * 4) = w2;
     }
     __syncthreads();
+    if (do_stats) {
+#pragma unroll
+      for (int ks = 0; ks < P / 32; ++ks) {
+        const bf16_t* lo = tile + (ks * 32 + 8 * tg + tq) * TS + wave * 16 + 4 * tp;
+        bf16x8 fr = tr_frag(lo, lo + 4 * TS);
+        st1 = mfma16(ones, fr, st1);
+        st2 = mfma16(fr, fr, st2);
+      }
+    }
     auto rowmap = [=](int row) -> long {
       int img = row / (TH * TW), ty = (row / TW) % TH, tx = row % TW;
       int n = img0 + img;
@@ -279,6 +310,13 @@ __global__ __launch_bounds__(256, 2) void igemm_s2_kernel(ConvArgs a) {
     epi.rows(a, tile, n0, P, rowmap);
   }
   EAE_STAMP(6);
+  if (do_stats) {
+    // st1: every accumulator row holds the column sums -> lanes 0..15 (row group 0, register 0)
+    // st2: the diagonal element of column j sits in lane 16*(j>>2) + j, register j&3
+    float* sp = a.stat_part + (size_t)blockIdx.x * 2 * COUT + n0 + wave * 16 + (lane & 15);
+    if (tg == 0) sp[0] = st1[0];
+    if (tg == tq) { float d = tp == 0 ? st2[0] : tp == 1 ? st2[1] : tp == 2 ? st2[2] : st2[3]; sp[COUT] = d; }
+  }
   epi.end(a, red, n0, blockIdx.x);
   EAE_STAMP(7);
 }
