@@ -5,7 +5,7 @@
 namespace {
 
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
-int launch(const ConvArgs& a, hipStream_t st) {
+int launch(const ConvArgs& a, hipStream_t st) {   // NOLINT
   auto kern = igemm_s2_kernel<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI>;
   constexpr size_t smem = igemm_smem<KIND, BN, TW, TH, NI>();
   static bool attr_done = false;
@@ -17,7 +17,9 @@ int launch(const ConvArgs& a, hipStream_t st) {
   const int Hpos = (KIND == KIND_CONV) ? a.Hin / 2 : a.Hin, Wpos = (KIND == KIND_CONV) ? a.Win / 2 : a.Win;
   const int groups = (a.B + NI - 1) / NI;
   dim3 grid(groups * (Hpos / TH) * (Wpos / TW), COUT / BN);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
+  ConvArgs b = a;
+  b.ntiles = (int)grid.x;
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, b);
   EAE_LAUNCH_CHECK();
   return 0;
 }

@@ -8,9 +8,11 @@ static int check_edge_shape(int B, int H, int W) {
   return 0;
 }
 
-int eae_launch_edge_conv(hipStream_t st, int src3_kind, int epi, const EdgeArgs& a) {
-  if (int rc = check_edge_shape(a.B, a.H, a.W)) return rc;
+int eae_launch_edge_conv(hipStream_t st, int src3_kind, int epi, const EdgeArgs& a0) {
+  if (int rc = check_edge_shape(a0.B, a0.H, a0.W)) return rc;
+  EdgeArgs a = a0;
   dim3 grid(a.B * (a.H / 2 / E_TH) * (a.W / 2 / E_TW));
+  a.c.ntiles = (int)grid.x;
 #define CASE(S, E) if (src3_kind == S && epi == E) { hipLaunchKernelGGL((edge_conv_kernel<S, E>), grid, dim3(256), 0, st, a); EAE_LAUNCH_CHECK(); return 0; }
   CASE(SRC3_NCHW_F32, EPI_FWD)
   CASE(SRC3_NHWC4_BF16, EPI_MASK)

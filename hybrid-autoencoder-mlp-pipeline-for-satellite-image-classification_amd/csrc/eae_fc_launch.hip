@@ -2,7 +2,9 @@
 #include "eae_internal.h"
 #include "eae_fc.cuh"
 
-int eae_launch_fc_nt(hipStream_t st, const FcNtArgs& a, int amode, int epi, int ksplit) {
+int eae_launch_fc_nt(hipStream_t st, const FcNtArgs& a0, int amode, int epi, int ksplit) {
+  FcNtArgs a = a0;
+  a.c.ntiles = ((a.M + 127) / 128) * (a.N / 256 > 0 ? a.N / 256 : 1);
   if (a.N % 64 || a.K % 64 || a.klen % 64 || a.klen * ksplit != a.K) return eae_set_error(-2, "fc_nt: N, K, klen must be multiples of 64");
   if (epi != FCE_PARTIAL && (a.N % 256 || ksplit != 1)) return eae_set_error(-2, "fc_nt: fused epilogues need N % 256 == 0 and no split-K");
   dim3 grid((a.M + 127) / 128, a.N / 64, ksplit);

@@ -27,7 +27,8 @@ struct ConvArgs {
   const bf16_t* wpack;     // [COUT][9][CIN] bf16 (tap = ky*3+kx)
   const float* bias;       // [COUT] (EPI_FWD) or nullptr
   bf16_t* out;             // NHWC bf16
-  float* stat_part;        // [ntiles][2][COUT] or nullptr (no statistics, e.g. eval mode)
+  float* stat_part;        // [2][COUT][ntiles] (channel-major: the finalize kernels read one channel contiguously) or nullptr
+  int ntiles;              // number of statistics partials per channel = workgroups along grid.x (set by the launcher)
   const bf16_t* yprev;     // EPI_MASK: raw pre-BN tensor at the output positions
   const float* prev_coef;  // EPI_MASK: [4][COUT] s,t,mean,invstd of that BN
   int B, Hin, Win;         // input spatial size (conv: out = Hin/2; deconv: out = 2*Hin)
@@ -117,7 +118,7 @@ struct TileEpilogue {
       int which = tid / BN, ch = tid % BN;
       float acc = 0.f;
       for (int r = 0; r < RPP; ++r) acc += red[(which * RPP + r) * BN + ch];
-      a.stat_part[((size_t)tile_id * 2 + which) * COUT + n0 + ch] = acc;
+      a.stat_part[((size_t)which * COUT + n0 + ch) * a.ntiles + tile_id] = acc;
     }
   }
 };
@@ -313,9 +314,9 @@ __global__ __launch_bounds__(256, 2) void igemm_s2_kernel(ConvArgs a) {
   if (do_stats) {
     // st1: every accumulator row holds the column sums -> lanes 0..15 (row group 0, register 0)
     // st2: the diagonal element of column j sits in lane 16*(j>>2) + j, register j&3
-    float* sp = a.stat_part + (size_t)blockIdx.x * 2 * COUT + n0 + wave * 16 + (lane & 15);
+    float* sp = a.stat_part + (size_t)(n0 + wave * 16 + (lane & 15)) * a.ntiles + blockIdx.x;
     if (tg == 0) sp[0] = st1[0];
-    if (tg == tq) { float d = tp == 0 ? st2[0] : tp == 1 ? st2[1] : tp == 2 ? st2[2] : st2[3]; sp[COUT] = d; }
+    if (tg == tq) { float d = tp == 0 ? st2[0] : tp == 1 ? st2[1] : tp == 2 ? st2[2] : st2[3]; sp[(size_t)COUT * a.ntiles] = d; }
   }
   epi.end(a, red, n0, blockIdx.x);
   EAE_STAMP(7);

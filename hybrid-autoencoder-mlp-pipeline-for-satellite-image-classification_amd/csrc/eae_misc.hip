@@ -6,49 +6,40 @@
 #include "eae_misc.h"
 
 
-// Sum the per-tile partials [ntiles][2][C] of 16 channels: 1024 threads = 16 channels x 64 tile lanes, fixed order.
-__device__ __forceinline__ void reduce_partials16(const float* __restrict__ part, int ntiles, int C, double (*r1)[17], double (*r2)[17],
-                                                  double& a, double& b) {
-  const int tid = threadIdx.x, cl = tid & 15, tl = tid >> 4;
-  const int ch = blockIdx.x * 16 + cl;
-  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  if (ch < C) {
-    int t = tl;
-    for (; t + 192 < ntiles; t += 256) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        s1[u] += (double)part[((size_t)(t + 64 * u) * 2 + 0) * C + ch];
-        s2[u] += (double)part[((size_t)(t + 64 * u) * 2 + 1) * C + ch];
-      }
-    }
-    for (; t < ntiles; t += 64) {
-      s1[0] += (double)part[((size_t)t * 2 + 0) * C + ch];
-      s2[0] += (double)part[((size_t)t * 2 + 1) * C + ch];
-    }
-  }
-  r1[tl][cl] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
-  r2[tl][cl] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+// Sum the partials of ONE channel: part = [2][C][ntiles] (channel-major, so the reads are contiguous); 256 threads stride
+// over the tiles, fp64 accumulation, fixed-order LDS tree -> bitwise reproducible.
+__device__ __forceinline__ void reduce_partials_ch(const float* __restrict__ part, int ntiles, int C, int ch, double* red,
+                                                   double& a, double& b) {
+  const int tid = threadIdx.x;
+  const float* p1 = part + (size_t)ch * ntiles;
+  const float* p2 = part + ((size_t)C + ch) * ntiles;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = tid; t < ntiles; t += 256) { s1 += (double)p1[t]; s2 += (double)p2[t]; }
+  red[tid] = s1; red[256 + tid] = s2;
   __syncthreads();
-  a = 0.0; b = 0.0;
-  if (tid < 16) for (int i = 0; i < 64; ++i) { a += r1[i][cl]; b += r2[i][cl]; }
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) { red[tid] += red[tid + o]; red[256 + tid] += red[256 + tid + o]; }
+    __syncthreads();
+  }
+  a = red[0]; b = red[256];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// BatchNorm forward finalize.  part = [ntiles][2][C] (sum y, sum y^2) -> coef [4][C] = s, t, mean, invstd
+// BatchNorm forward finalize.  part = [2][C][ntiles] (sum y, sum y^2) -> coef [4][C] = s, t, mean, invstd
 //   s = gamma*invstd, t = beta - mean*s  so that  BN(y) = s*y + t           (nn.BatchNorm2d, eps 1e-5, R.md:293)
 // running_mean/var updated with momentum (unbiased variance), num_batches_tracked += 1   
-// grid = ceil(C/16) blocks of 1024 threads: 16 channels x 64 strided tile lanes, fixed summation order.
+// grid = C blocks (one channel each) of 256 threads.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int ntiles, int C, float count,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int ntiles, int C, float count,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* running_mean, float* running_var, long long* nbt,
                                                            float momentum, float eps, float* __restrict__ coef) {
-  __shared__ double r1[64][17], r2[64][17];
-  const int tid = threadIdx.x, cl = tid & 15;
-  const int ch = blockIdx.x * 16 + cl;
+  __shared__ double red[512];
+  const int tid = threadIdx.x;
+  const int ch = blockIdx.x;
   double a, b;
-  reduce_partials16(part, ntiles, C, r1, r2, a, b);
-  if (tid < 16 && ch < C) {
+  reduce_partials_ch(part, ntiles, C, ch, red, a, b);
+  if (tid == 0) {
     double mean = a / count;
     double var = b / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -80,18 +71,18 @@ __global__ void bn_eval_coef_kernel(int C, const float* gamma, const float* beta
   coef[3 * C + ch] = invstd;
 }
 
-// BatchNorm backward finalize.  part = [ntiles][2][C] (sum g, sum g*xhat), g = ReLU-masked upstream gradient.
+// BatchNorm backward finalize.  part = [2][C][ntiles] (sum g, sum g*xhat), g = ReLU-masked upstream gradient.
 //   dbeta = sum g ; dgamma = sum g*xhat ;  dy = A*g + B*y + Cc  with
 //   A = gamma*invstd, B = -A*invstd*dgamma/N, Cc = -A*dbeta/N + A*invstd*mean*dgamma/N   (native_batch_norm_backward)
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int ntiles, int C, float count,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int ntiles, int C, float count,
                                                                const float* __restrict__ gamma, const float* __restrict__ coef_fwd,
                                                                float* dgamma, float* dbeta, float* __restrict__ coef_bwd) {
-  __shared__ double r1[64][17], r2[64][17];
-  const int tid = threadIdx.x, cl = tid & 15;
-  const int ch = blockIdx.x * 16 + cl;
+  __shared__ double red[512];
+  const int tid = threadIdx.x;
+  const int ch = blockIdx.x;
   double a, b;
-  reduce_partials16(part, ntiles, C, r1, r2, a, b);
-  if (tid < 16 && ch < C) {
+  reduce_partials_ch(part, ntiles, C, ch, red, a, b);
+  if (tid == 0) {
     float db = (float)a, dg = (float)b;
     if (dbeta) dbeta[ch] = db;
     if (dgamma) dgamma[ch] = dg;
@@ -106,7 +97,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 
 int eae_launch_bn_finalize(hipStream_t st, const float* part, int ntiles, int C, long long count, const float* gamma,
                            const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, part, ntiles, C, (float)count, gamma, beta, rm,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, part, ntiles, C, (float)count, gamma, beta, rm,
                      rv, nbt, momentum, eps, coef);
   EAE_LAUNCH_CHECK();
   return 0;
@@ -119,7 +110,7 @@ int eae_launch_bn_eval_coef(hipStream_t st, int C, const float* gamma, const flo
 }
 int eae_launch_bn_bwd_finalize(hipStream_t st, const float* part, int ntiles, int C, long long count, const float* gamma,
                                const float* coef_fwd, float* dgamma, float* dbeta, float* coef_bwd) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, part, ntiles, C, (float)count, gamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, part, ntiles, C, (float)count, gamma,
                      coef_fwd, dgamma, dbeta, coef_bwd);
   EAE_LAUNCH_CHECK();
   return 0;

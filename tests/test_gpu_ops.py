@@ -52,14 +52,14 @@ def test_conv_s2_raw_fwd(lib, B, H):
     xd = G.to_nhwc_bf16(x)
     out = torch.empty((B, H // 2, H // 2, 64), dtype=torch.bfloat16, device=G.dev())
     nt = lib.eae_op_conv_s2_ntiles(0, B, H, H)
-    part = torch.zeros((nt, 2, 64), dtype=torch.float32, device=G.dev())
+    part = torch.zeros((2, 64, nt), dtype=torch.float32, device=G.dev())
     bd = G.f32(b)
     check(lib.eae_op_conv_s2(G.stream(), 0, G.src(0, xd), 32, 64, B, H, H, G.ptr(p1), G.ptr(bd), G.ptr(out), G.ptr(part), 0, None, None))
     torch.cuda.synchronize()
     ref = O.conv_s2_fwd(x, w, b)
     got = G.from_nhwc(out)
     assert np.abs(got - ref).max() <= 2 ** -7 * np.abs(ref).max() + 1e-3, G.relmax(got, ref)
-    ps = part.cpu().numpy().sum(0)
+    ps = part.cpu().numpy().sum(2)
     np.testing.assert_allclose(ps[0], got.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
     np.testing.assert_allclose(ps[1], (got.astype(np.float64) ** 2).sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
 
@@ -76,14 +76,14 @@ def test_deconv_s2_raw_fwd(lib, B, H):
     xd = G.to_nhwc_bf16(x)
     out = torch.empty((B, 2 * H, 2 * H, 32), dtype=torch.bfloat16, device=G.dev())
     nt = lib.eae_op_conv_s2_ntiles(1, B, H, H)
-    part = torch.zeros((nt, 2, 32), dtype=torch.float32, device=G.dev())
+    part = torch.zeros((2, 32, nt), dtype=torch.float32, device=G.dev())
     bd = G.f32(b)
     check(lib.eae_op_conv_s2(G.stream(), 1, G.src(0, xd), 64, 32, B, H, H, G.ptr(p2), G.ptr(bd), G.ptr(out), G.ptr(part), 0, None, None))
     torch.cuda.synchronize()
     ref = O.deconv_s2_fwd(x, w, b)
     got = G.from_nhwc(out)
     assert np.abs(got - ref).max() <= 2 ** -7 * np.abs(ref).max() + 1e-3, G.relmax(got, ref)
-    ps = part.cpu().numpy().sum(0)
+    ps = part.cpu().numpy().sum(2)
     np.testing.assert_allclose(ps[0], got.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
 
 
@@ -119,13 +119,13 @@ def test_edge_conv_and_wgrad(lib):
     xd, bd = G.f32(x), G.f32(b)
     out = torch.empty((B, 32, 32, 32), dtype=torch.bfloat16, device=G.dev())
     nt = B * 8
-    part = torch.zeros((nt, 2, 32), dtype=torch.float32, device=G.dev())
+    part = torch.zeros((2, 32, nt), dtype=torch.float32, device=G.dev())
     check(lib.eae_op_edge_conv(G.stream(), 0, G.ptr(xd), B, 64, 64, G.ptr(wpd), G.ptr(bd), G.ptr(out), G.ptr(part), 0, None, None))
     torch.cuda.synchronize()
     ref = O.conv_s2_fwd(O.bf16_round(x), wq, b)
     got = G.from_nhwc(out)
     assert np.abs(got - ref).max() <= 2 ** -7 * np.abs(ref).max() + 1e-3, G.relmax(got, ref)
-    np.testing.assert_allclose(part.cpu().numpy().sum(0)[0], got.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(part.cpu().numpy().sum(2)[0], got.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
     # weight gradient with a plain (raw) side tensor
     dy = O.bf16_round(rng.standard_normal((B, 32, 32, 32)).astype(np.float32))
     dyd = G.to_nhwc_bf16(dy)
