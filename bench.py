@@ -74,7 +74,15 @@ def kernel_roofline(eng, step_fn, batch):
     """Per-launch duration of the dominant kernel measured with HIP events on the launch stream inside real train steps,
     priced against its bounding roofline with ALGORITHMIC bytes (DESIGN.md section 'Roofline accounting')."""
     from eae_amd import profile_hooks as PH
-    return PH.dominant_kernel_roofline(eng, step_fn, batch, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFLOPS)
+    r = PH.dominant_kernel_roofline(eng, step_fn, batch, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFLOPS)
+    # HBM traffic of that kernel from the PMC counters: collected with rocprofv3 in separate --pmc passes of this same
+    # command (they cannot be read from inside the process) and committed under profiles/
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_b512.json")
+    if batch == BATCH and os.path.exists(pmc):
+        k = json.load(open(pmc))["kernels"].get("void igemm_s2_kernel<0, 32, 64, 64, 16, 8, 1, 1, 0>(ConvArgs)")
+        if k:
+            r["traffic"] = k["traffic_bytes"]
+    return r
 
 
 def main():

@@ -171,3 +171,32 @@ def test_determinism():
         torch.cuda.synchronize()
         outs.append(eng.params.cpu().numpy().copy())
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_data_parallel_trainer_world1_rccl():
+    """The DP step (grad_step -> bucketed all-reduce over RCCL -> adam_step) on a 1-rank NCCL group equals the fused
+    single-GPU train_step bit for bit (the multi-rank arithmetic is covered on CPU by tests/test_dp_gloo.py)."""
+    import os
+    import torch.distributed as dist
+    from eae_amd import dp
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        x, y = gu.make_images(8, 100)
+        ma, mb = _model(), _model()
+        ea, eb = _engine(ma), _engine(mb)
+        tr = dp.DataParallelTrainer(eb)
+        tr.broadcast_parameters()
+        for _ in range(2):
+            ea.train_step(_cuda(x), _cuda(y), 35.0, 5e-3)
+            tr.train_step(_cuda(x), _cuda(y), 35.0, 5e-3)
+        torch.cuda.synchronize()
+        assert torch.equal(ea.params, eb.params)
+    finally:
+        if created:
+            dist.destroy_process_group()
