@@ -37,6 +37,7 @@ _PROTOS = {
     "eae_set_adam_step": (C.c_int, [vp, C.c_longlong]),
     "eae_get_adam_step": (C.c_longlong, [vp]),
     "eae_ae_forward": (C.c_int, [vp, vp, C.POINTER(EaeStepIO)]),
+    "eae_ae_backward": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     "eae_ae_grad_step": (C.c_int, [vp, vp, C.POINTER(EaeStepIO)]),
     "eae_adam_step": (C.c_int, [vp, vp, C.c_float, C.c_float]),
     "eae_ae_train_step": (C.c_int, [vp, vp, C.POINTER(EaeStepIO), C.c_float]),
@@ -61,6 +62,7 @@ _PROTOS = {
     "eae_mlp_bind": (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
     "eae_mlp_set_adam_step": (C.c_int, [vp, C.c_longlong]),
     "eae_mlp_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_ulonglong, vp, vp]),
+    "eae_mlp_backward": (C.c_int, [vp, vp, vp, C.c_int, C.c_ulonglong, vp, vp]),
     "eae_mlp_train_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_ulonglong, vp, vp, vp]),
     "eae_mlp_eval_step": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp]),
 }

@@ -127,7 +127,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   size_t o_wscr = carve(c->wscratch_floats * 4);
   const int ksplit = (int)(c->K / 128);
   size_t o_fcp = carve((size_t)ksplit * Bm * c->L * 4);
-  size_t o_mse = carve((size_t)eae_edge_tiles((int)Bm, c->H, c->W) * 4 * 4);
+  size_t o_mse = carve(std::max((size_t)eae_edge_tiles((int)Bm, c->H, c->W), (size_t)((Bm * c->H * c->W + 255) / 256)) * 4 * 4);
   const long long hb = eae_head_blocks((int)Bm);
   c->head_stride = r4(128LL * c->L) + 128 + r4(128LL * c->C) + r4(c->C);
   size_t o_ce = carve(hb * 2 * 4), o_head = carve(hb * c->head_stride * 4), o_loss = carve(64 * 4);
@@ -278,7 +278,7 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
   f.M = B; f.N = c->L; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
   const int ksplit = (int)(c->K / 128);
   RC(eae_launch_fc_nt(st, f, SRC_BNRELU, FCE_PARTIAL, ksplit));
-  RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, c->P + c->poff[17], nullptr, c->z));
+  RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, c->P + c->poff[17], nullptr, nullptr, c->z));
   return 0;
 }
 
@@ -314,8 +314,9 @@ int run_decoder(eae_ctx* c, hipStream_t st, const float* z, int B, bool train, c
   return 0;
 }
 
-int run_head(eae_ctx* c, hipStream_t st, int B, const long long* labels, float* logits, bool want_grad) {
+int run_head(eae_ctx* c, hipStream_t st, int B, const long long* labels, float* logits, bool want_grad, const float* dlogits_in = nullptr) {
   HeadArgs h = HeadArgs();
+  h.dlogits_in = dlogits_in;
   h.z = c->z; h.w1 = c->P + c->poff[34]; h.b1 = c->P + c->poff[35]; h.w2 = c->P + c->poff[36]; h.b2 = c->P + c->poff[37];
   h.labels = labels; h.B = B; h.L = c->L; h.C = c->C; h.inv_batch = 1.0f / (float)B;
   h.logits = logits; h.dz = c->dzc; h.grad_part = want_grad ? c->headpart : nullptr; h.grad_stride = c->head_stride;
@@ -339,6 +340,7 @@ int check_io(eae_ctx* c, const eae_step_io* io, bool need_grad) {
 int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_grad) {
   const int B = io->B;
   const bool train = io->train != 0;
+  c->fwd_ready = train; c->fwd_B = B; c->fwd_head = io->head; c->fwd_x = io->x;
   RC(ensure_packed(c, st));
   RC(run_encoder(c, st, io->x, B, train));
   const double numel = (double)B * 3.0 * c->H * c->W;
@@ -356,7 +358,7 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
   return 0;
 }
 
-int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io) {
+int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float* dz_ext = nullptr) {
   const int B = io->B, H = c->H, W = c->W;
   const bool head = io->head != 0;
   // ---- classifier weight gradients (partials written by the head kernel)
@@ -415,7 +417,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io) {
     f.M = B; f.N = c->L; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
     const int ksplit = (int)(c->K / 128);
     RC(eae_launch_fc_nt(st, f, SRC_RAW, FCE_PARTIAL, ksplit));
-    RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, nullptr, head ? c->dzc : nullptr, c->dz));
+    RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, nullptr, head ? c->dzc : nullptr, dz_ext, c->dz));
   }
   // ---- enc.fc: weight/bias gradient and backward-data into y[3]'s BN+ReLU
   {
@@ -460,8 +462,27 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io) {
 
 extern "C" int eae_ae_forward(eae_ctx* c, void* stream, const eae_step_io* io) {
   RC(check_io(c, io, false));
-  c->fwd_ready = false;
   return forward_impl(c, (hipStream_t)stream, io, false);
+}
+
+// Backward of the most recent TRAIN-mode eae_ae_forward for externally supplied output gradients (the autograd path:
+// `loss.backward()` on a torch loss built from x_hat / logits / z, R.md:649-653).  Activations of that forward are still
+// resident in the workspace.  Any of dx_hat / dlogits / dz may be NULL (= zero).
+extern "C" int eae_ae_backward(eae_ctx* c, void* stream, const float* x_hat, const float* dx_hat, const float* dlogits, const float* dz) {
+  if (!c || !c->G) return eae_set_error(EAE_ERR_STATE, "backward: no gradient arena bound");
+  if (!c->fwd_ready) return eae_set_error(EAE_ERR_STATE, "backward: no train-mode forward is resident (call eae_ae_forward with train=1 first)");
+  if (!x_hat || !dx_hat) return eae_set_error(EAE_ERR_ARG, "backward: x_hat and dx_hat are required");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = c->fwd_B;
+  eae_step_io io = eae_step_io();
+  io.x = c->fwd_x; io.B = B; io.train = 1; io.head = (dlogits != nullptr) ? 1 : 0;
+  RC(eae_launch_sigmoid_bwd(st, x_hat, dx_hat, c->g4, c->msepart, B, c->H, c->W));
+  const int nblk = (int)(((long long)B * c->H * c->W + 255) / 256);
+  RC(eae_launch_loss_finalize(st, c->msepart, nblk, nullptr, 0, 0.f, 1.0, B, c->G + c->poff[33], nullptr, nullptr));
+  if (dlogits) RC(run_head(c, st, B, nullptr, nullptr, true, dlogits));
+  RC(backward_impl(c, st, &io, dz));
+  c->fwd_ready = false;
+  return 0;
 }
 
 extern "C" int eae_ae_grad_step(eae_ctx* c, void* stream, const eae_step_io* io) {

@@ -56,3 +56,40 @@ int eae_launch_deconv4_loss(hipStream_t st, int smode, const Deconv4Args& a) {
   EAE_LAUNCH_CHECK();
   return 0;
 }
+
+// g4[n,oy,ox,c] = bf16(dx_hat * x_hat * (1 - x_hat))   (backward of nn.Sigmoid, R.md:383, for an externally supplied dL/dx_hat)
+// fp32 NCHW in, bf16 NHWC4 out; part[block][4] = {0, sum g(c=0), sum g(c=1), sum g(c=2)} (bias gradient of deconv4)
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ xh, const float* __restrict__ dxh, bf16_t* __restrict__ g4,
+                                                           float* __restrict__ part, long npix_total, long plane) {
+  __shared__ float red[4][4];
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;      // pixel index n*H*W + oy*W + ox
+  float g[3] = {0.f, 0.f, 0.f};
+  if (p < npix_total) {
+    const long n = p / plane, r = p % plane;
+    uint32_t w[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float x = xh[(n * 3 + c) * plane + r];
+      w[c] = f2bf(dxh[(n * 3 + c) * plane + r] * x * (1.0f - x));
+      g[c] = bf2f(w[c]);
+    }
+    *reinterpret_cast<uint2*>(g4 + p * 4) = make_uint2(w[0] | (w[1] << 16), w[2]);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) g[c] += __shfl_xor(g[c], o);
+    if (lane == 0) red[wave][c + 1] = g[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    part[(size_t)blockIdx.x * 4 + threadIdx.x] = threadIdx.x == 0 ? 0.f : red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+int eae_launch_sigmoid_bwd(hipStream_t st, const float* x_hat, const float* dx_hat, void* g4, float* part, int B, int H, int W) {
+  const long plane = (long)H * W, tot = plane * B;
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, x_hat, dx_hat, (bf16_t*)g4, part, tot, plane);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}

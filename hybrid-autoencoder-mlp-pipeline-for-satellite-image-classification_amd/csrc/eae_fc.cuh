@@ -131,12 +131,13 @@ __global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs a) {
 // z (or dz) = bias + sum over K-slices of the split-K partials (+ optional addend), fp32
 static __global__ __launch_bounds__(256) void fc_splitk_reduce_kernel(const float* __restrict__ part, int nsl, int M, int N,
                                                                 const float* __restrict__ bias, const float* __restrict__ addend,
-                                                                float* __restrict__ out) {
+                                                                const float* __restrict__ addend2, float* __restrict__ out) {
   long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)M * N) return;
   float s = bias ? bias[i % N] : 0.f;
   for (int k = 0; k < nsl; ++k) s += part[(long)k * M * N + i];
   if (addend) s += addend[i];
+  if (addend2) s += addend2[i];
   out[i] = s;
 }
 

@@ -5,6 +5,7 @@ struct HeadArgs {
   const float* z;          // [B][L] fp32 latent
   const float *w1, *b1, *w2, *b2;   // classifier.0 [128][L],[128]; classifier.2 [C][128],[C]  (fp32 master weights)
   const long long* labels; // int64 [B] or nullptr (forward only)
+  const float* dlogits_in; // [B][C] externally supplied dL/dlogits (autograd path) or nullptr
   int B, L, C;
   float inv_batch;         // 1/B (CrossEntropyLoss mean reduction)
   float* logits;           // [B][C] or nullptr

@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
       for (int c = 0; c < C; ++c) se += expf(lg[tid * 16 + c] - mx);
       float lse = logf(se) + mx;
       if (a.logits) for (int c = 0; c < C; ++c) a.logits[(size_t)r * C + c] = lg[tid * 16 + c];
-      if (a.labels) {
+      if (a.dlogits_in) {
+        for (int c = 0; c < C; ++c) lg[tid * 16 + c] = a.dlogits_in[(size_t)r * C + c];
+      } else if (a.labels) {
         int lab = (int)a.labels[r];
         loss = lse - lg[tid * 16 + lab];
         correct = (am == lab) ? 1.f : 0.f;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
     for (int r = 0; r < HR; ++r) { s += rl[r]; cr += rl[HR + r]; }
     a.loss_part[blockIdx.x * 2] = s; a.loss_part[blockIdx.x * 2 + 1] = cr;
   }
-  if (!a.labels || !a.grad_part) return;
+  if ((!a.labels && !a.dlogits_in) || !a.grad_part) return;
   {   // dh[r][j] = (h_pre > 0) * sum_c dlogits[r][c] * W2[c][j]
     const int j = tid & 127, rh = tid >> 7;
     for (int r = rh * (HR / 2); r < (rh + 1) * (HR / 2); ++r) {

@@ -25,5 +25,7 @@ int eae_launch_deconv4_loss(hipStream_t st, int smode, const Deconv4Args& a);
 int eae_launch_wgrad_s2(hipStream_t st, const WgradArgs& a, int cs, int cb, int smode, int bmode, float* scratch,
                         long long scratch_floats, float* dw);
 int eae_launch_fc_nt(hipStream_t st, const FcNtArgs& a, int amode, int epi, int ksplit);
-int eae_launch_fc_reduce(hipStream_t st, const float* part, int nsl, int M, int N, const float* bias, const float* addend, float* out);
+int eae_launch_fc_reduce(hipStream_t st, const float* part, int nsl, int M, int N, const float* bias, const float* addend,
+                         const float* addend2, float* out);
+int eae_launch_sigmoid_bwd(hipStream_t st, const float* x_hat, const float* dx_hat, void* g4, float* part, int B, int H, int W);
 int eae_launch_fc_tn(hipStream_t st, const FcTnArgs& a, int pmode, int qmode);

@@ -25,6 +25,8 @@ struct MlpArgs {
   float step_size, bc2_sqrt, b1, b2, eps, wd;
   unsigned long long seed, step;
   const float* drop_mask;
+  const float* dlog_in;    // externally supplied dL/dlogits [B][C] (autograd path) or nullptr
+  int update_running;      // 0: do not touch running statistics / num_batches_tracked (recompute pass of the autograd path)
   float p_drop;
   float* logits; float* stats;    // stats: += loss*B, += B, += correct
 };
@@ -110,10 +112,12 @@ __global__ __launch_bounds__(T) void mlp_kernel(MlpArgs a) {
     if (tid < H1) {
       inv1[tid] = 1.0f / sqrtf(var1[tid] + BN_EPS);
       float unb = nb > 1 ? var1[tid] * nb / (nb - 1) : var1[tid];
-      a.bnrun[tid] = (1.f - BN_MOM) * a.bnrun[tid] + BN_MOM * mean1[tid];
-      a.bnrun[H1 + tid] = (1.f - BN_MOM) * a.bnrun[H1 + tid] + BN_MOM * unb;
+      if (a.update_running) {
+        a.bnrun[tid] = (1.f - BN_MOM) * a.bnrun[tid] + BN_MOM * mean1[tid];
+        a.bnrun[H1 + tid] = (1.f - BN_MOM) * a.bnrun[H1 + tid] + BN_MOM * unb;
+      }
     }
-    if (tid == 0 && a.nbt) { a.nbt[0] += 1; a.nbt[1] += 1; }
+    if (tid == 0 && a.nbt && a.update_running) { a.nbt[0] += 1; a.nbt[1] += 1; }
   } else if (tid < H1) {
     mean1[tid] = a.bnrun[tid];
     inv1[tid] = 1.0f / sqrtf(a.bnrun[H1 + tid] + BN_EPS);
@@ -146,8 +150,10 @@ __global__ __launch_bounds__(T) void mlp_kernel(MlpArgs a) {
     if (tid < H2) {
       inv2[tid] = 1.0f / sqrtf(var2[tid] + BN_EPS);
       float unb = nb > 1 ? var2[tid] * nb / (nb - 1) : var2[tid];
-      a.bnrun[2 * H1 + tid] = (1.f - BN_MOM) * a.bnrun[2 * H1 + tid] + BN_MOM * mean2[tid];
-      a.bnrun[2 * H1 + H2 + tid] = (1.f - BN_MOM) * a.bnrun[2 * H1 + H2 + tid] + BN_MOM * unb;
+      if (a.update_running) {
+        a.bnrun[2 * H1 + tid] = (1.f - BN_MOM) * a.bnrun[2 * H1 + tid] + BN_MOM * mean2[tid];
+        a.bnrun[2 * H1 + H2 + tid] = (1.f - BN_MOM) * a.bnrun[2 * H1 + H2 + tid] + BN_MOM * unb;
+      }
     }
   } else if (tid < H2) {
     mean2[tid] = a.bnrun[2 * H1 + tid];
@@ -168,8 +174,13 @@ __global__ __launch_bounds__(T) void mlp_kernel(MlpArgs a) {
     if (a.logits) a.logits[(size_t)(r0 + b) * C + c] = s;
   }
   __syncthreads();
-  if (!a.labels) return;
+  if (a.dlog_in) {
+    for (int i = tid; i < nb * C; i += T) dlog[(i / C) * 16 + (i % C)] = a.dlog_in[(size_t)r0 * C + i];
+    __syncthreads();
+  }
+  if (!a.labels && !a.dlog_in) return;
   float loss = 0.f, corr = 0.f;
+  if (!a.dlog_in)
   for (int b = tid; b < nb; b += T) {
     float* l = dlog + b * 16;
     float mx = l[0]; int am = 0;
@@ -318,12 +329,13 @@ extern "C" int eae_mlp_bind(eae_mlp* m, float* params, float* grads, float* adam
 extern "C" int eae_mlp_set_adam_step(eae_mlp* m, long long s) { if (!m) return eae_set_error(EAE_ERR_ARG, "mlp is NULL"); m->adam_step = s; return 0; }
 
 static int mlp_launch(eae_mlp* m, hipStream_t st, const float* x, const long long* labels, int B, int train, int backward, int adam,
-                      float lr, float wd, unsigned long long seed, const float* drop_mask, float* logits, float* stats) {
+                      float lr, float wd, unsigned long long seed, const float* drop_mask, float* logits, float* stats,
+                      const float* dlog_in = nullptr) {
   if (!m || !x) return eae_set_error(EAE_ERR_ARG, "mlp: NULL argument");
   if (!m->P) return eae_set_error(EAE_ERR_STATE, "eae_mlp_bind has not been called");
   if (B <= 0 || B > m->Bm) return eae_set_error(EAE_ERR_ARG, "mlp: batch size outside 1..max_batch");
   if (train && B < 2) return eae_set_error(EAE_ERR_ARG, "mlp: BatchNorm1d in training mode needs more than 1 sample per batch");
-  if (backward && (!m->G || !labels)) return eae_set_error(EAE_ERR_STATE, "mlp: gradient arena and labels required");
+  if (backward && (!m->G || (!labels && !dlog_in))) return eae_set_error(EAE_ERR_STATE, "mlp: gradient arena and labels (or dlogits) required");
   if (adam && (!m->M || !m->V)) return eae_set_error(EAE_ERR_STATE, "mlp: Adam moment arenas required");
   MlpArgs a;
   a.x = x; a.labels = labels; a.B = B; a.IN = m->IN; a.C = m->C;
@@ -339,7 +351,7 @@ static int mlp_launch(eae_mlp* m, hipStream_t st, const float* x, const long lon
     a.step_size = (float)(lr / bc1); a.bc2_sqrt = (float)std::sqrt(bc2);
   }
   a.seed = seed; a.step = (unsigned long long)m->adam_step; a.drop_mask = drop_mask; a.p_drop = 0.3f;
-  a.logits = logits; a.stats = stats;
+  a.logits = logits; a.stats = stats; a.dlog_in = dlog_in; a.update_running = dlog_in ? 0 : 1;
   const int grid = train ? 1 : (B + 63) / 64;
   hipLaunchKernelGGL(mlp_kernel, dim3(grid), dim3(T), 0, st, a);
   EAE_LAUNCH_CHECK();
@@ -356,4 +368,13 @@ extern "C" int eae_mlp_train_step(eae_mlp* m, void* stream, const float* x, cons
 }
 extern "C" int eae_mlp_eval_step(eae_mlp* m, void* stream, const float* x, const long long* labels, int B, float* logits, float* stats) {
   return mlp_launch(m, (hipStream_t)stream, x, labels, B, 0, 0, 0, 0.f, 0.f, 0, nullptr, logits, stats);
+}
+
+// loss.backward() for a torch-side loss on the logits (R.md:2644-2645): recomputes the train-mode forward of the SAME batch
+// (same dropout mask: the Philox key is (seed, optimisation step); running statistics are not touched again) and
+// back-propagates the supplied dL/dlogits; gradients land in the gradient arena.
+extern "C" int eae_mlp_backward(eae_mlp* m, void* stream, const float* x, int B, unsigned long long seed, const float* drop_mask,
+                                const float* dlogits) {
+  if (!dlogits) return eae_set_error(EAE_ERR_ARG, "mlp_backward: dlogits is NULL");
+  return mlp_launch(m, (hipStream_t)stream, x, nullptr, B, 1, 1, 0, 0.f, 0.f, seed, drop_mask, nullptr, nullptr, dlogits);
 }

@@ -260,6 +260,42 @@ def engine_for(module, max_batch=None):
     return eng
 
 
+class _AEFunction(torch.autograd.Function):
+    """Autograd bridge for hand-written loops (the reference's own: `x_hat, logits, _ = model(imgs)` ... `loss.backward()`,
+    R.md:647-653): forward = eae_ae_forward, backward = eae_ae_backward with the gradients of (x_hat, logits, z).  The
+    parameter gradients are returned to autograd (which accumulates them into `.grad` like for any torch module)."""
+
+    @staticmethod
+    def forward(ctx, eng, x, *params):
+        x_hat, logits, z = eng.forward(x, train=True, head=True)
+        ctx.eng = eng
+        ctx.save_for_backward(x_hat)
+        ctx.nparams = len(params)
+        ctx.need = [p.requires_grad for p in params]
+        return x_hat, logits, z
+
+    @staticmethod
+    def backward(ctx, dx_hat, dlogits, dz):
+        eng = ctx.eng
+        (x_hat,) = ctx.saved_tensors
+        dev = eng.device
+
+        def prep(t, like_shape):
+            if t is None:
+                return None
+            return t.to(dtype=torch.float32).contiguous()
+
+        dx_hat = prep(dx_hat, None)
+        if dx_hat is None:
+            dx_hat = torch.zeros_like(x_hat)
+        dlogits, dz = prep(dlogits, None), prep(dz, None)
+        check(eng.lib.eae_ae_backward(eng.ctx, _stream(), _ptr(x_hat), _ptr(dx_hat), _ptr(dlogits), _ptr(dz)))
+        grads = []
+        for (p, i), need in zip(eng._slots, ctx.need):
+            grads.append(eng.grads[eng.poff[i]: eng.poff[i] + p.numel()].view(p.shape).clone() if need else None)
+        return (None, None, *grads)
+
+
 class _ModuleFacade:
     """What the nn.Module shells call (modules.py).  Inference / no-grad forward of the reference signatures."""
 
@@ -267,15 +303,19 @@ class _ModuleFacade:
     def _check_grad(module, *tensors):
         if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
             raise RuntimeError(
-                "differentiating through Module.forward with an external torch loss is not supported by the HIP engine "
-                "yet: use eae_amd.train.train_step / fit_autoencoder (fused alpha*MSE + CE step, R.md:646-654), or call "
-                "forward under torch.no_grad()")
+                "autograd through a stand-alone Encoder / Decoder is not supported by the HIP engine: differentiate through the "
+                "owning SupervisedAutoencoder (R.md:647), use fit_autoencoder / AEEngine.train_step, or call forward under "
+                "torch.no_grad()")
 
 
 def autoencoder_forward(module, x):
-    _ModuleFacade._check_grad(module)
     eng = engine_for(module)
     eng.params_changed()
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        if not module.training:
+            raise RuntimeError("differentiating through an eval-mode SupervisedAutoencoder (BatchNorm with running statistics) is "
+                               "not supported by the HIP engine; call model.train() or use torch.no_grad()")
+        return _AEFunction.apply(eng, x, *[p for p, _ in eng._slots])
     x_hat, logits, z = eng.forward(x, train=module.training, head=True)
     return x_hat, logits, z
 

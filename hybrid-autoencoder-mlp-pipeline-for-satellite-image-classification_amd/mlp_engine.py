@@ -129,10 +129,38 @@ def mlp_engine_for(mlp, max_batch=None):
     return eng
 
 
+class _MLPFunction(torch.autograd.Function):
+    """Autograd bridge for the reference's own MLP loop (`logits = clf(xb)` ... `loss.backward()`, R.md:2643-2645)."""
+
+    @staticmethod
+    def forward(ctx, eng, x, *params):
+        x = x.contiguous()
+        eng._autograd_calls = getattr(eng, "_autograd_calls", 0) + 1
+        seed = (eng.seed + eng._autograd_calls) & 0xFFFFFFFFFFFFFFFF      # fresh dropout mask per forward call
+        logits = torch.empty((x.shape[0], eng.classes), dtype=torch.float32, device=eng.device)
+        check(eng.lib.eae_mlp_forward(eng.ctx, _stream(), _ptr(x), x.shape[0], 1, seed, None, _ptr(logits)))
+        ctx.eng, ctx.seed = eng, seed
+        ctx.save_for_backward(x)
+        ctx.need = [p.requires_grad for p in params]
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng = ctx.eng
+        (x,) = ctx.saved_tensors
+        dlogits = dlogits.to(torch.float32).contiguous()
+        check(eng.lib.eae_mlp_backward(eng.ctx, _stream(), _ptr(x), x.shape[0], ctx.seed, None, _ptr(dlogits)))
+        grads = [eng.grads[eng.poff[i]: eng.poff[i] + p.numel()].view(p.shape).clone() if need else None
+                 for (p, i), need in zip(eng._slots, ctx.need)]
+        return (None, None, *grads)
+
+
 def mlp_forward(module, x):
-    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        raise RuntimeError(
-            "differentiating through MLP.forward with an external torch loss is not supported by the HIP engine yet: use "
-            "eae_amd.fit_mlp / MLPEngine.train_step (fused CE + Adam step, R.md:2641-2646), or call forward under torch.no_grad()")
     eng = mlp_engine_for(module, max_batch=max(256, x.shape[0]))
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        if not module.training:
+            raise RuntimeError("differentiating through an eval-mode MLP is not supported by the HIP engine; call clf.train() "
+                               "or use torch.no_grad()")
+        eng._check(x)
+        return _MLPFunction.apply(eng, x, *[p for p, _ in eng._slots])
     return eng.forward(x, train=module.training)

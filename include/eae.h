@@ -76,6 +76,10 @@ typedef struct eae_step_io {
 
 /* x_hat, logits, z = model(x) (R.md:647 / 673), plus the loss terms when io->x target / labels are given. */
 int eae_ae_forward(eae_ctx* ctx, void* stream, const eae_step_io* io);
+/* loss.backward() for a torch-side loss (R.md:649-653): backward of the most recent train-mode eae_ae_forward given the
+ * gradients of its outputs (fp32; dx_hat [B,3,H,W], dlogits [B,C] or NULL, dz [B,L] or NULL); x_hat = that forward's output.
+ * Gradients of all 38 tensors land in the grad arena (biases in front of a BatchNorm: exact zeros). */
+int eae_ae_backward(eae_ctx* ctx, void* stream, const float* x_hat, const float* dx_hat, const float* dlogits, const float* dz);
 /* zero_grad + forward + loss + backward (R.md:646-653): gradients of all 38 tensors land in the grad arena. */
 int eae_ae_grad_step(eae_ctx* ctx, void* stream, const eae_step_io* io);
 /* optimizer.step() of torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) over the bound arenas (R.md:624, 654). */
@@ -144,6 +148,10 @@ int eae_mlp_set_adam_step(eae_mlp* m, long long step);
  * caller-supplied keep-mask [B][128] (fp32 0/1) when drop_mask != NULL. */
 int eae_mlp_forward(eae_mlp* m, void* stream, const float* x, int B, int train, unsigned long long seed,
                     const float* drop_mask, float* logits);
+/* loss.backward() for a torch-side loss on the logits of the preceding train-mode eae_mlp_forward of the same batch
+ * (R.md:2644-2645); gradients land in the gradient arena. */
+int eae_mlp_backward(eae_mlp* m, void* stream, const float* x, int B, unsigned long long seed, const float* drop_mask,
+                     const float* dlogits);
 /* one iteration of R.md:2641-2649: zero_grad, forward, CE, backward, Adam(lr, weight_decay);
  * stats: float[8] += loss*B, B, #correct. */
 int eae_mlp_train_step(eae_mlp* m, void* stream, const float* x, const long long* labels, int B, float lr,

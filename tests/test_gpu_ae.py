@@ -200,3 +200,35 @@ def test_data_parallel_trainer_world1_rccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_autograd_drop_in_loop_matches_fused_step(golden):
+    """The reference's own loop shape (R.md:646-654): torch losses + loss.backward() + torch.optim.Adam on the module
+    shells.  Gradients must equal the fused eae_ae_grad_step path (same kernels; only sigmoid/MSE/CE run in torch)."""
+    import torch.nn as nn
+    g = golden("ae_fwd_bwd_b8.npz")
+    x, y = _cuda(g["x"]), _cuda(g["labels"])
+    alpha = float(g["alpha"])
+    m1, m2 = _model(), _model()
+    e1 = _engine(m1)
+    e1.grad_step(x, y, alpha)
+    e1.expose_grads()
+    m2.train()
+    opt = torch.optim.Adam(m2.parameters(), lr=5e-3)
+    opt.zero_grad()
+    x_hat, logits, _ = m2(x)
+    loss = alpha * nn.MSELoss()(x_hat, x) + nn.CrossEntropyLoss()(logits, y)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 0.02 * abs(float(g["loss"]))
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        a, b = p1.grad.cpu().numpy(), p2.grad.cpu().numpy()
+        scale = max(1e-12, np.abs(a).max())
+        # the fused path rounds the loss gradient to bf16 at the same point; tiny differences come from fp32 sigmoid/MSE in torch
+        assert np.abs(a - b).max() <= 2e-2 * scale, (n1, np.abs(a - b).max() / scale)
+    w0 = m2.enc.encoder[0].weight.detach().clone()
+    opt.step()
+    assert not torch.equal(w0, m2.enc.encoder[0].weight)
+    with torch.no_grad():          # parameters were changed by a torch optimizer: the next forward repacks them
+        m2.eval()
+        xh2, _, _ = m2(x)
+    assert torch.isfinite(xh2).all()
