@@ -9,6 +9,7 @@
 #include <vector>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 static thread_local std::string g_err;
 int eae_set_error(int code, const char* msg) { g_err = msg ? msg : "unknown error"; return code; }
@@ -68,6 +69,14 @@ struct eae_ctx {
   PackDesc* descs_dev = nullptr;
   int ndesc = 0;
   size_t pk_c1, pk_p1[6], pk_p2[6], pk_d4j, pk_d4k, pk_we1, pk_we2, pk_wd1, pk_wd2, pk_bd;
+  // second stream: weight-gradient kernels, the classifier head and the slice reductions do not sit on the
+  // forward / backward-data dependency chain, so they run concurrently with it (fork/join through events)
+  hipStream_t side = nullptr;
+  static constexpr int NEV = 16;
+  hipEvent_t ev_fork[NEV] = {};
+  hipEvent_t ev_join = nullptr;
+  int ev_i = 0;
+  bool use_side = true;
   // optional in-situ timing of the dominant kernel (enc.conv2 forward) with HIP events on the launch stream
   static constexpr int PROF_RING = 64;
   bool prof_on = false;
@@ -169,6 +178,13 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   e = hipMemcpy(c->descs_dev, descs.data(), descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(c->g4, 0, Bm * (size_t)c->H * c->W * 4 * 2);
   if (e != hipSuccess) { hipFree(c->ws); delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
+  c->use_side = getenv("EAE_NO_SIDE_STREAM") == nullptr;
+  if (c->use_side) {
+    e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    for (int i = 0; i < eae_ctx::NEV && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (e != hipSuccess) { hipFree(c->ws); delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
+  }
   *out = c;
   return 0;
 }
@@ -200,6 +216,11 @@ extern "C" int eae_destroy(eae_ctx* c) {
   if (!c) return 0;
   hipDeviceSynchronize();
   if (c->prof_ev[0]) for (int i = 0; i < 2 * eae_ctx::PROF_RING; ++i) hipEventDestroy(c->prof_ev[i]);
+  if (c->side) {
+    for (int i = 0; i < eae_ctx::NEV; ++i) hipEventDestroy(c->ev_fork[i]);
+    hipEventDestroy(c->ev_join);
+    hipStreamDestroy(c->side);
+  }
   if (c->ws) hipFree(c->ws);
   delete c;
   return 0;
@@ -221,6 +242,24 @@ extern "C" long long eae_get_adam_step(eae_ctx* c) { return c ? c->adam_step : -
 namespace {
 
 #define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+// fork: work enqueued on the returned stream starts after everything enqueued so far on `st`
+int fork_side(eae_ctx* c, hipStream_t st, hipStream_t* out) {
+  if (!c->use_side) { *out = st; return 0; }
+  hipEvent_t ev = c->ev_fork[c->ev_i];
+  c->ev_i = (c->ev_i + 1) % eae_ctx::NEV;
+  EAE_HIP(hipEventRecord(ev, st));
+  EAE_HIP(hipStreamWaitEvent(c->side, ev, 0));
+  *out = c->side;
+  return 0;
+}
+// join: work enqueued on `st` from now on starts after everything enqueued so far on the side stream
+int join_side(eae_ctx* c, hipStream_t st) {
+  if (!c->use_side) return 0;
+  EAE_HIP(hipEventRecord(c->ev_join, c->side));
+  EAE_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
+  return 0;
+}
 
 int ensure_packed(eae_ctx* c, hipStream_t st) {
   if (c->packed) return 0;
@@ -346,9 +385,14 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
   const double numel = (double)B * 3.0 * c->H * c->W;
   const float gscale = (float)(2.0 * io->alpha / numel);
   const bool want_loss = io->loss_accum || io->loss_last;
-  RC(run_decoder(c, st, c->z, B, train, (want_loss || want_grad) ? io->x : nullptr, gscale, io->x_hat, want_grad, want_loss));
   const bool head = io->head != 0;
-  if (head) RC(run_head(c, st, B, io->labels, io->logits, want_grad));
+  if (head) {          // the head only needs z: it runs beside the decoder
+    hipStream_t ss;
+    RC(fork_side(c, st, &ss));
+    RC(run_head(c, ss, B, io->labels, io->logits, want_grad));
+  }
+  RC(run_decoder(c, st, c->z, B, train, (want_loss || want_grad) ? io->x : nullptr, gscale, io->x_hat, want_grad, want_loss));
+  if (head) RC(join_side(c, st));
   if (io->z) EAE_HIP(hipMemcpyAsync(io->z, c->z, (size_t)B * c->L * 4, hipMemcpyDeviceToDevice, st));
   if (want_loss || want_grad) {
     const int n_ce = (head && io->labels) ? eae_head_blocks(B) : 0;
@@ -361,17 +405,19 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
 int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float* dz_ext = nullptr) {
   const int B = io->B, H = c->H, W = c->W;
   const bool head = io->head != 0;
+  hipStream_t ss;       // side stream: everything that only feeds the optimizer (weight gradients and their reductions)
+  RC(fork_side(c, st, &ss));
   // ---- classifier weight gradients (partials written by the head kernel)
   if (head) {
     const int nb = eae_head_blocks(B);
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(c->head_stride / 4)), dim3(256), 0, st, c->headpart, nb,
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(c->head_stride / 4)), dim3(256), 0, ss, c->headpart, nb,
                        (long)(c->head_stride / 4), c->G + c->poff[34], 1.0f);
     EAE_LAUNCH_CHECK();
   } else {
-    EAE_HIP(hipMemsetAsync(c->G + c->poff[34], 0, (size_t)(c->poff[38] - c->poff[34]) * 4, st));
+    EAE_HIP(hipMemsetAsync(c->G + c->poff[34], 0, (size_t)(c->poff[38] - c->poff[34]) * 4, ss));
   }
   // ---- deconv4: weight gradient, then backward-data into u[2]'s BN+ReLU
-  RC(eae_launch_edge_wgrad(st, SRC3_NHWC4_BF16, c->g4, B, H, W, src_bnrelu(c->u[2], c->coef_f[6]), SRC_BNRELU, c->wscratch,
+  RC(eae_launch_edge_wgrad(ss, SRC3_NHWC4_BF16, c->g4, B, H, W, src_bnrelu(c->u[2], c->coef_f[6]), SRC_BNRELU, c->wscratch,
                            c->wscratch_floats, c->G + c->poff[32]));
   {
     EdgeArgs a;
@@ -391,7 +437,8 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     w.small = (i == 0) ? src_raw(c->d0) : src_bnrelu(c->u[i - 1], c->coef_f[3 + i]);
     w.big = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
     w.B = B; w.Hs = Hs; w.Ws = Ws;
-    RC(eae_launch_wgrad_s2(st, w, cs, cb, i == 0 ? SRC_RAW : SRC_BNRELU, SRC_BNBWD, c->wscratch, c->wscratch_floats,
+    RC(fork_side(c, st, &ss));       // needs coef_b[4+i] (BN-backward finalize of this layer's output)
+    RC(eae_launch_wgrad_s2(ss, w, cs, cb, i == 0 ? SRC_RAW : SRC_BNRELU, SRC_BNBWD, c->wscratch, c->wscratch_floats,
                            c->G + c->poff[20 + 4 * i]));
     ConvArgs a = ConvArgs();
     a.src = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
@@ -411,7 +458,8 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     FcTnArgs t = FcTnArgs();
     t.p = src_raw(c->gd0); t.q = src_f32(c->z); t.Bt = B; t.I = (int)c->K; t.J = c->L;
     t.out = c->G + c->poff[18]; t.colsum = c->G + c->poff[19]; t.out_mode = 0; t.Pn = (int)c->Pn;
-    RC(eae_launch_fc_tn(st, t, SRC_RAW, SRC_F32));
+    RC(fork_side(c, st, &ss));       // needs gd0
+    RC(eae_launch_fc_tn(ss, t, SRC_RAW, SRC_F32));
     FcNtArgs f = FcNtArgs();
     f.a = src_raw(c->gd0); f.w = (const bf16_t*)(c->pack + c->pk_wd2);
     f.M = B; f.N = c->L; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
@@ -424,7 +472,8 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     FcTnArgs t = FcTnArgs();
     t.p = src_f32(c->dz); t.q = src_bnrelu(c->y[3], c->coef_f[3]); t.Bt = B; t.I = c->L; t.J = (int)c->K;
     t.out = c->G + c->poff[16]; t.colsum = c->G + c->poff[17]; t.out_mode = 1; t.Pn = (int)c->Pn;
-    RC(eae_launch_fc_tn(st, t, SRC_F32, SRC_BNRELU));
+    RC(fork_side(c, st, &ss));       // needs dz
+    RC(eae_launch_fc_tn(ss, t, SRC_F32, SRC_BNRELU));
     FcNtArgs f = FcNtArgs();
     f.a = src_f32(c->dz); f.w = (const bf16_t*)(c->pack + c->pk_we2);
     f.M = B; f.N = (int)c->K; f.K = c->L; f.klen = c->L;
@@ -441,7 +490,8 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     w.small = src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
     w.big = src_bnrelu(c->y[i - 1], c->coef_f[i - 1]);
     w.B = B; w.Hs = Hs; w.Ws = Ws;
-    RC(eae_launch_wgrad_s2(st, w, cs, cb, SRC_BNBWD, SRC_BNRELU, c->wscratch, c->wscratch_floats, c->G + c->poff[4 * i]));
+    RC(fork_side(c, st, &ss));       // needs coef_b[i]
+    RC(eae_launch_wgrad_s2(ss, w, cs, cb, SRC_BNBWD, SRC_BNRELU, c->wscratch, c->wscratch_floats, c->G + c->poff[4 * i]));
     ConvArgs a = ConvArgs();
     a.src = src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
     a.wpack = (const bf16_t*)(c->pack + c->pk_p2[i - 1]);
@@ -451,8 +501,10 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     RC(bn_bwd_fin(c, st, i - 1, eae_conv_s2_ntiles(1, B, Hs, Ws), (long long)B * (Hs * 2) * (Ws * 2)));
   }
   // ---- conv1 weight gradient
-  RC(eae_launch_edge_wgrad(st, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, c->wscratch,
+  RC(fork_side(c, st, &ss));         // needs coef_b[0]
+  RC(eae_launch_edge_wgrad(ss, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, c->wscratch,
                            c->wscratch_floats, c->G + c->poff[0]));
+  RC(join_side(c, st));
   // Biases in front of a BatchNorm have an identically zero gradient (the reference computes ~1e-9 rounding noise);
   // their slots in the gradient arena are zeroed once in eae_bind and never written.
   return 0;
