@@ -43,6 +43,7 @@ _PROTOS = {
     "eae_ae_train_step": (C.c_int, [vp, vp, C.POINTER(EaeStepIO), C.c_float]),
     "eae_encoder_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "eae_decoder_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    "eae_debug_copy": (C.c_int, [vp, C.c_int, vp, C.c_longlong]),
     "eae_profile_enable": (C.c_int, [vp, C.c_int]),
     "eae_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), c_ll_p]),
     "eae_op_conv_s2": (C.c_int, [vp, C.c_int, EaeSrc, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]),

@@ -128,17 +128,32 @@ __global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs a) {
   else tile_epilogue<256, 64, EPI_PLAIN>(a.c, al, red, c0, tile_id, 128, rowmap);
 }
 
-// z (or dz) = bias + sum over K-slices of the split-K partials (+ optional addend), fp32
+// z (or dz) = bias + sum over K-slices of the split-K partials (+ optional addends), fp32; 16 float4 lanes x 16 slice
+// lanes per block, fixed summation order
 static __global__ __launch_bounds__(256) void fc_splitk_reduce_kernel(const float* __restrict__ part, int nsl, int M, int N,
                                                                 const float* __restrict__ bias, const float* __restrict__ addend,
                                                                 const float* __restrict__ addend2, float* __restrict__ out) {
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long)M * N) return;
-  float s = bias ? bias[i % N] : 0.f;
-  for (int k = 0; k < nsl; ++k) s += part[(long)k * M * N + i];
-  if (addend) s += addend[i];
-  if (addend2) s += addend2[i];
-  out[i] = s;
+  __shared__ float4 red[16][16];
+  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  const long n4 = (long)M * N / 4;
+  const long i = (long)blockIdx.x * 16 + lx;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4)
+    for (int k = ly; k < nsl; k += 16) {
+      float4 v = reinterpret_cast<const float4*>(part)[(long)k * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  red[ly][lx] = s;
+  __syncthreads();
+  if (ly == 0 && i < n4) {
+    float4 r = red[0][lx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { r.x += red[k][lx].x; r.y += red[k][lx].y; r.z += red[k][lx].z; r.w += red[k][lx].w; }
+    if (bias) { float4 b = *reinterpret_cast<const float4*>(bias + (i * 4) % N); r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w; }
+    if (addend) { float4 b = reinterpret_cast<const float4*>(addend)[i]; r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w; }
+    if (addend2) { float4 b = reinterpret_cast<const float4*>(addend2)[i]; r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w; }
+    reinterpret_cast<float4*>(out)[i] = r;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -19,8 +19,8 @@ int eae_launch_fc_nt(hipStream_t st, const FcNtArgs& a0, int amode, int epi, int
 
 int eae_launch_fc_reduce(hipStream_t st, const float* part, int nsl, int M, int N, const float* bias, const float* addend,
                          const float* addend2, float* out) {
-  long n = (long)M * N;
-  hipLaunchKernelGGL(fc_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, nsl, M, N, bias, addend, addend2, out);
+  long n4 = (long)M * N / 4;
+  hipLaunchKernelGGL(fc_splitk_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, part, nsl, M, N, bias, addend, addend2, out);
   EAE_LAUNCH_CHECK();
   return 0;
 }

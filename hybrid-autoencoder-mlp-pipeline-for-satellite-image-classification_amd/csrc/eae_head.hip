@@ -148,27 +148,28 @@ int eae_launch_head(hipStream_t st, const HeadArgs& a) {
 //   accum[0] += loss*B, accum[1] += mse*B, accum[2] += ce*B, accum[3] += B, accum[4] += correct
 //   last[0..2] = loss, mse, ce of this step
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void loss_finalize_kernel(const float* mse_part, int n_mse, const float* ce_part, int n_ce, float alpha,
-                                     float inv_numel, float B, float* db4, float* accum, float* last) {
-  __shared__ double red[256][4];
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* mse_part, int n_mse, const float* ce_part, int n_ce, float alpha,
+                                                             float inv_numel, float B, float* db4, float* accum, float* last) {
+  __shared__ double red[256][6];
   const int tid = threadIdx.x;
-  double s[4] = {0, 0, 0, 0};
-  for (int i = tid; i < n_mse; i += 256)
-    for (int k = 0; k < 4; ++k) s[k] += (double)mse_part[(size_t)i * 4 + k];
-  for (int k = 0; k < 4; ++k) red[tid][k] = s[k];
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < n_mse; i += 256) {
+    float4 v = reinterpret_cast<const float4*>(mse_part)[i];
+    s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+  }
+  for (int i = tid; i < n_ce; i += 256) { s[4] += ce_part[i * 2]; s[5] += ce_part[i * 2 + 1]; }
+  for (int k = 0; k < 6; ++k) red[tid][k] = s[k];
   __syncthreads();
   for (int o = 128; o >= 1; o >>= 1) {
-    if (tid < o) for (int k = 0; k < 4; ++k) red[tid][k] += red[tid + o][k];
+    if (tid < o) for (int k = 0; k < 6; ++k) red[tid][k] += red[tid + o][k];
     __syncthreads();
   }
   if (tid == 0) {
-    double ce = 0, corr = 0;
-    for (int i = 0; i < n_ce; ++i) { ce += ce_part[i * 2]; corr += ce_part[i * 2 + 1]; }
     float mse = (float)(red[0][0] * inv_numel);
-    float cem = n_ce ? (float)(ce / B) : 0.f;
+    float cem = n_ce ? (float)(red[0][4] / B) : 0.f;
     float loss = alpha * mse + cem;
     if (db4) { db4[0] = (float)red[0][1]; db4[1] = (float)red[0][2]; db4[2] = (float)red[0][3]; }
-    if (accum) { accum[0] += loss * B; accum[1] += mse * B; accum[2] += cem * B; accum[3] += B; accum[4] += (float)corr; }
+    if (accum) { accum[0] += loss * B; accum[1] += mse * B; accum[2] += cem * B; accum[3] += B; accum[4] += (float)red[0][5]; }
     if (last) { last[0] = loss; last[1] = mse; last[2] = cem; }
   }
 }

@@ -214,6 +214,50 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Same update with the per-step scalars (lr/bias_correction1, sqrt(bias_correction2), weight decay) read from device memory,
+// so that a captured hipGraph of the whole train step can be replayed while the step count advances.
+__global__ __launch_bounds__(256) void adam_dyn_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long n4, float b1, float b2, float eps,
+                                                        const float* __restrict__ dyn) {
+  const float step_size = dyn[0], bc2_sqrt = dyn[1], wd = dyn[2];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gj = G[j] + wd * P[j];
+      M[j] = M[j] + (1.f - b1) * (gj - M[j]);
+      V[j] = b2 * V[j] + (1.f - b2) * gj * gj;
+      float denom = sqrtf(V[j]) / bc2_sqrt + eps;
+      P[j] -= step_size * (M[j] / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+}
+__global__ void set_dyn_kernel(float* dyn, float a, float b, float c) { dyn[0] = a; dyn[1] = b; dyn[2] = c; }
+
+int eae_launch_adam_dyn(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double b1, double b2, double eps,
+                        const float* dyn) {
+  if (n % 4) return eae_set_error(-2, "adam: arena length must be a multiple of 4");
+  long n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_dyn_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4, (float)b1, (float)b2, (float)eps, dyn);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+int eae_launch_set_dyn(hipStream_t st, float* dyn, double lr, double b1, double b2, double wd, long long step) {
+  double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+  hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, st, dyn, (float)(lr / bc1), (float)sqrt(bc2), (float)wd);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+
 int eae_launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
                     double eps, double wd, long long step) {
   if (n % 4) return eae_set_error(-2, "adam: arena length must be a multiple of 4");

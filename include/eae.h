@@ -95,6 +95,8 @@ int eae_decoder_forward(eae_ctx* ctx, void* stream, const float* z, int B, int t
  * HIP events are recorded on the launch stream around that launch for up to 64 steps; eae_profile_read synchronises them
  * and returns the summed kernel time and the number of launches measured (bench.py's `roofline` object). */
 int eae_profile_enable(eae_ctx* ctx, int on);
+/* diagnostic: copy an internal fp32 buffer (0 z, 1 dz, 2 dz_head, 3 head partials, 4 CE partials) to dst (device) */
+int eae_debug_copy(eae_ctx* ctx, int which, float* dst, long long n);
 int eae_profile_read(eae_ctx* ctx, double* total_ms, long long* count);
 
 /* ------------------------------------------------------------------ per-op entry points ---------------------- */

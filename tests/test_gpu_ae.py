@@ -232,3 +232,32 @@ def test_autograd_drop_in_loop_matches_fused_step(golden):
         m2.eval()
         xh2, _, _ = m2(x)
     assert torch.isfinite(xh2).all()
+
+
+def test_graph_replay_equals_eager():
+    """With EAE_GRAPH=1, from the third call with the same buffers the train step is replayed from a captured hipGraph;
+    the result must be bit-identical to the eager launch sequence."""
+    import os
+    x, y = gu.make_images(8, 100)
+    xd, yd = _cuda(x), _cuda(y)
+    res = []
+    for no_graph in (False, True):
+        if no_graph:
+            os.environ.pop("EAE_GRAPH", None)
+        else:
+            os.environ["EAE_GRAPH"] = "1"
+        try:
+            m = _model()
+            eng = _engine(m)
+            for s in range(7):
+                eng.train_step(xd, yd, 35.0, 5e-3)
+            torch.cuda.synchronize()
+            res.append((eng.params.cpu().numpy().copy(), eng.bn_running.cpu().numpy().copy(), eng.loss_accum.cpu().numpy().copy(),
+                        int(m.state_dict()["enc.encoder.1.num_batches_tracked"])))
+        finally:
+            os.environ.pop("EAE_GRAPH", None)
+    assert np.array_equal(res[0][0], res[1][0]), np.abs(res[0][0] - res[1][0]).max()
+    assert np.array_equal(res[0][1], res[1][1]), np.abs(res[0][1] - res[1][1]).max()
+    assert np.array_equal(res[0][2], res[1][2]), (res[0][2], res[1][2])
+    assert res[0][3] == res[1][3] == 7
+    assert np.isfinite(res[0][0]).all()
