@@ -165,7 +165,7 @@ struct Geo {
 };
 
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
-__global__ __launch_bounds__(256, 2) void igemm_s2_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (CIN > 64 ? 1 : 2)) void igemm_s2_kernel(ConvArgs a) {
   using G = Geo<KIND, TW, TH, NI>;
   static_assert(G::P == 64 || G::P == 128, "tile must hold 64 or 128 positions");
   static_assert(CIN % 32 == 0 && COUT % BN == 0 && (BN == 32 || BN == 64), "shape");
@@ -206,45 +206,65 @@ __global__ __launch_bounds__(256, 2) void igemm_s2_kernel(ConvArgs a) {
   SrcRsrc rs;
   rs.init<SRC>(a.src);
 
-  for (int chunk = 0; chunk < CIN / 32; ++chunk) {
-    if (chunk) __syncthreads();
-    // ---- weight fragments of all 9 taps of this K-chunk (registers; L1/L2 resident)
-    bf16x8 wf[9];
+  // ---- patch pieces of this thread: piece q = tid + 256*i covers patch pixel q/4, channels kgs*8.. of the current
+  //      K-chunk; consecutive i advance the pixel by 64 -> (img, row, col) are updated incrementally.  Byte offsets are
+  //      32-bit; out-of-image pieces use the hardware-checked out-of-range offset (no branches); both are chunk-independent.
+  constexpr int NC = CIN / 32;
+  uint32_t boff[NPA];
+  bool val[NPA];
+  {
+    constexpr int DR = (64 / PW) % PH, DC = 64 % PW, DI = 64 / (PH * PW);
+    int pix = tid >> 2;
+    int img = pix / (PH * PW), rem = pix % (PH * PW);
+    int pr = rem / PW, pc = rem % PW;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) wf[tap] = *reinterpret_cast<const bf16x8*>(wrow + tap * CIN + chunk * 32);
-    // ---- stage the input patch (transform applied once per element).  Piece q = tid + 256*i covers patch pixel q/4,
-    //      channels kgs*8..; consecutive i advance the pixel by 64 -> (img, row, col) are updated incrementally, the
-    //      byte offset is 32-bit and out-of-image pieces use the hardware-checked out-of-range offset (no branches).
-    ChanCoef<SRC> cc;
-    cc.load(a.src.coef, CIN, chunk * 32 + kgs * 8);
-    RawPiece<SRC> raw[NPA];
-    bool val[NPA];
-    {
-      constexpr int DR = (64 / PW) % PH, DC = 64 % PW, DI = 64 / (PH * PW);
-      int pix = tid >> 2;
-      int img = pix / (PH * PW), rem = pix % (PH * PW);
-      int pr = rem / PW, pc = rem % PW;
-#pragma unroll
-      for (int i = 0; i < NPA; ++i) {
-        int iy = iy0 + pr, ix = ix0 + pc, n = img0 + img;
-        val[i] = (tid + i * 256 < NPIX * 4) && (n < a.B) && ((unsigned)iy < (unsigned)a.Hin) && ((unsigned)ix < (unsigned)a.Win);
-        uint32_t boff = ((uint32_t)((n * a.Hin + iy) * a.Win + ix) * CIN + chunk * 32 + kgs * 8) * 2u;
-        load_piece_b<SRC>(rs, val[i] ? boff : OOB_OFF, raw[i]);
-        pc += DC; pr += DR; img += DI;
-        if (pc >= PW) { pc -= PW; pr += 1; }
-        if (pr >= PH) { pr -= PH; img += 1; }
-      }
+    for (int i = 0; i < NPA; ++i) {
+      int iy = iy0 + pr, ix = ix0 + pc, n = img0 + img;
+      val[i] = (tid + i * 256 < NPIX * 4) && (n < a.B) && ((unsigned)iy < (unsigned)a.Hin) && ((unsigned)ix < (unsigned)a.Win);
+      boff[i] = val[i] ? ((uint32_t)((n * a.Hin + iy) * a.Win + ix) * CIN + kgs * 8) * 2u : OOB_OFF;
+      pc += DC; pr += DR; img += DI;
+      if (pc >= PW) { pc -= PW; pr += 1; }
+      if (pr >= PH) { pr -= PH; img += 1; }
     }
-    EAE_STAMP(1);
+  }
+  // Software pipeline over the K-chunks (register double-buffering): the raw patch pieces and the 9 weight fragments of
+  // chunk c+1 are requested right after the barrier that publishes chunk c, so their latency hides behind the MFMA phase.
+  bf16x8 wnext[9];
+  RawPiece<SRC> raw[NPA];
+  ChanCoef<SRC> cc;
+  // prefetch requests are issued in NOFF slices, one after each offset's MFMA group, so that the vector-memory pipe
+  // (the 64 B/clk L1 path is the scarce resource of the multi-chunk layers) drains while the matrix pipe works
+  auto issue_slice = [&](int chunk, int o) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+      if (tap % G::NOFF == o) wnext[tap] = *reinterpret_cast<const bf16x8*>(wrow + tap * CIN + chunk * 32);
+    if (o == 0) cc.load(a.src.coef, CIN, chunk * 32 + kgs * 8);
+#pragma unroll
+    for (int i = 0; i < NPA; ++i)
+      if (i % G::NOFF == o) load_piece_b<SRC>(rs, val[i] ? boff[i] + chunk * 64 : OOB_OFF, raw[i]);
+  };
+  auto issue = [&](int chunk) {
+#pragma unroll
+    for (int o = 0; o < G::NOFF; ++o) issue_slice(chunk, o);
+  };
+  issue(0);
+#pragma unroll
+  for (int chunk = 0; chunk < NC; ++chunk) {
+    EAE_STAMP(8 + chunk * 4 + 0);
+    // ---- stage the input patch of this chunk (transform applied once per element)
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       int q = tid + i * 256;
       if (q < NPIX * 4)
         *reinterpret_cast<uint4*>(patch + (q >> 2) * PIX_STRIDE + kgs * 8) = transform_piece<SRC>(raw[i], val[i], cc);
     }
-    EAE_STAMP(2);
+    bf16x8 wf[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) wf[tap] = wnext[tap];
+    EAE_STAMP(8 + chunk * 4 + 1);
     __syncthreads();
-    EAE_STAMP(3);
+    EAE_STAMP(8 + chunk * 4 + 2);
+    EAE_STAMP(8 + chunk * 4 + 3);
     // ---- MFMAs: for every distinct patch offset, read the pixel fragments once and feed all taps that use it
 #pragma unroll
     for (int o = 0; o < G::NOFF; ++o) {
@@ -258,7 +278,9 @@ __global__ __launch_bounds__(256, 2) void igemm_s2_kernel(ConvArgs a) {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) acc[G::tap_phase(tap)][mi] = mfma16(wf[tap], pf[mi], acc[G::tap_phase(tap)][mi]);
       }
+      if (chunk + 1 < NC) issue_slice(chunk + 1, o);
     }
+    if (chunk + 1 < NC) __syncthreads();
   }
   // ---- epilogue: per phase, accumulators (lane = pixel, 4 consecutive channels in regs) -> LDS tile -> global
   EAE_STAMP(4);

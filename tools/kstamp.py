@@ -17,7 +17,7 @@ lib = _lib.load()
 raw = C.CDLL(_lib.LIB_PATH)
 B = 512
 dev = torch.device("cuda:0")
-dbg = torch.zeros(16, dtype=torch.int64, device=dev)
+dbg = torch.zeros(64, dtype=torch.int64, device=dev)
 names = ["loads issued+coef", "transform+LDSwrite", "barrier", "MFMA(last chunk)", "barrier", "tile+rows(all ph)", "stats reduce"]
 for (kind, ci, co, hin) in ((0, 32, 64, 32), (0, 64, 128, 16), (0, 128, 256, 8), (1, 128, 64, 8), (1, 64, 32, 16)):
     x = (torch.randn((B, hin, hin, ci), device=dev) * 0.5).to(torch.bfloat16)
@@ -33,5 +33,11 @@ for (kind, ci, co, hin) in ((0, 32, 64, 32), (0, 64, 128, 16), (0, 128, 256, 8),
             check(lib.eae_op_conv_s2(G.stream(), kind, G.src(1, x, None, cf), ci, co, B, hin, hin, G.ptr(w), G.ptr(bias), G.ptr(out), G.ptr(part), 0, None, None))
         torch.cuda.synchronize()
         t = dbg.cpu().tolist()
-        d = [t[i + 1] - t[i] for i in range(7)]
-        print(f"kind{kind} {ci}->{co} in{hin} blk {blk}: total {t[7]-t[0]} | " + " | ".join(f"{n}: {v}" for n, v in zip(names, d)))
+        nc = ci // 32
+        msg = [f"kind{kind} {ci}->{co} in{hin} blk {blk}: total {t[7]-t[0]}", f"start->chunk0 stage begin {t[8]-t[0]}"]
+        for c in range(nc):
+            b = 8 + c * 4
+            nxt = t[8 + (c + 1) * 4] if c + 1 < nc else t[4]
+            msg.append(f"c{c}: stage {t[b+1]-t[b]} bar {t[b+2]-t[b+1]} issue {t[b+3]-t[b+2]} mfma(+bar) {nxt-t[b+3]}")
+        msg.append(f"epilogue {t[7]-t[4]}")
+        print(" | ".join(msg))
