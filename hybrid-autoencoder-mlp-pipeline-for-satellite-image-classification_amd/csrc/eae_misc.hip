@@ -193,7 +193,7 @@ int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, co
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n4, float b1, float b2, float step_size,
-                                                    float bc2_sqrt, float eps, float wd) {
+                                                    float bc2_sqrt, float eps, float wd, float gscale) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
     float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float gj = G[j] + wd * P[j];
+      float gj = G[j] * gscale + wd * P[j];
       M[j] = M[j] + (1.f - b1) * (gj - M[j]);            // exp_avg.lerp_(grad, 1-beta1)
       V[j] = b2 * V[j] + (1.f - b2) * gj * gj;            // mul_(beta2).addcmul_(grad, grad, 1-beta2)
       float denom = sqrtf(V[j]) / bc2_sqrt + eps;
@@ -260,13 +260,18 @@ int eae_launch_set_dyn(hipStream_t st, float* dyn, double lr, double b1, double 
 
 int eae_launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
                     double eps, double wd, long long step) {
+  return eae_launch_adam_scaled(st, p, g, m, v, n, lr, b1, b2, eps, wd, step, 1.0f);
+}
+
+int eae_launch_adam_scaled(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
+                           double eps, double wd, long long step, float gscale) {
   if (n % 4) return eae_set_error(-2, "adam: arena length must be a multiple of 4");
   double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
   long n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4, (float)b1, (float)b2, (float)(lr / bc1),
-                     (float)sqrt(bc2), (float)eps, (float)wd);
+                     (float)sqrt(bc2), (float)eps, (float)wd, gscale);
   EAE_LAUNCH_CHECK();
   return 0;
 }

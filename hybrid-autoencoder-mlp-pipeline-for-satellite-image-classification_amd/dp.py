@@ -43,6 +43,7 @@ class DataParallelTrainer:
         self.eng.params_changed()
 
     def allreduce_gradients(self):
+        """Sum the gradient arena over the ranks (buckets in backward order) and scale by 1/world."""
         handles = []
         for lo, hi in self.buckets:
             handles.append(dist.all_reduce(self.eng.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
@@ -51,6 +52,25 @@ class DataParallelTrainer:
         self.eng.grads.mul_(1.0 / self.world)
 
     def train_step(self, x, labels, alpha, lr, head=True):
-        self.eng.grad_step(x, labels, alpha, head=head)
-        self.allreduce_gradients()
-        self.eng.adam_step(lr)
+        """One data-parallel iteration.  With the HIP engine the all-reduce of the decoder-side gradients (tensors 18..37, the
+        first bucket in backward order) is enqueued behind the engine's side stream as soon as that half of the backward has
+        been launched, so RCCL moves it over xGMI while the encoder half is still computing; the encoder-side bucket follows
+        after the second half.  The 1/world scaling is folded into the Adam kernel."""
+        eng = self.eng
+        side = eng.side_stream() if hasattr(eng, "grad_step_begin") and hasattr(eng, "side_stream") else None
+        if side is None:                       # engines without the split API (CPU stand-in of the gloo test)
+            eng.grad_step(x, labels, alpha, head=head)
+            self.allreduce_gradients()
+            eng.adam_step(lr)
+            return
+        cut = eng.poff[18]
+        total = eng.poff[38]
+        eng.grad_step_begin(x, labels, alpha, head=head)
+        with torch.cuda.stream(side):          # ordered after the side stream's work enqueued so far
+            h1 = dist.all_reduce(eng.grads[cut:total], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        eng.grad_step_end()
+        with torch.cuda.stream(side):
+            h2 = dist.all_reduce(eng.grads[0:cut], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        h1.wait()                              # the current (main) stream waits for both collectives
+        h2.wait()
+        eng.adam_step(lr, grad_scale=1.0 / self.world)

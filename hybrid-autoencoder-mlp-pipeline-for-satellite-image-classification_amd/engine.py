@@ -180,8 +180,23 @@ class AEEngine:
         io, keep = self._io(x, labels, True, head, alpha, x_hat)
         check(self.lib.eae_ae_grad_step(self.ctx, _stream(), C.byref(io)))
 
-    def adam_step(self, lr, weight_decay=0.0):
-        check(self.lib.eae_adam_step(self.ctx, _stream(), float(lr), float(weight_decay)))
+    def adam_step(self, lr, weight_decay=0.0, grad_scale=1.0):
+        check(self.lib.eae_adam_step_scaled(self.ctx, _stream(), float(lr), float(weight_decay), float(grad_scale)))
+
+    def grad_step_begin(self, x, labels, alpha, head=True):
+        """forward + loss + backward of classifier / decoder / dec.fc: gradient tensors 18..37 complete behind the side stream"""
+        io, keep = self._io(x, labels, True, head, alpha)
+        self._keep = keep
+        check(self.lib.eae_ae_grad_step_begin(self.ctx, _stream(), C.byref(io)))
+
+    def grad_step_end(self):
+        check(self.lib.eae_ae_grad_step_end(self.ctx, _stream()))
+        self._keep = None
+
+    def side_stream(self):
+        """The engine's side stream as a torch ExternalStream (None when side-stream concurrency is disabled)."""
+        h = self.lib.eae_side_stream(self.ctx)
+        return torch.cuda.ExternalStream(h, device=self.device) if h else None
 
     def train_step(self, x, labels, alpha, lr, head=True, x_hat=None):
         """One iteration of the reference's batch loop (R.md:646-657); the loss is accumulated on the device."""

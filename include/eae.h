@@ -84,6 +84,14 @@ int eae_ae_backward(eae_ctx* ctx, void* stream, const float* x_hat, const float*
 int eae_ae_grad_step(eae_ctx* ctx, void* stream, const eae_step_io* io);
 /* optimizer.step() of torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) over the bound arenas (R.md:624, 654). */
 int eae_adam_step(eae_ctx* ctx, void* stream, float lr, float weight_decay);
+/* Data-parallel training (new work, no reference counterpart): the gradient step in two halves.  After _begin the gradient
+ * tensors 18..37 (dec.fc, decoder, classifier) are complete once the engine's side stream (eae_side_stream) has drained, so
+ * their all-reduce can be enqueued behind that stream and overlap with _end (enc.fc + encoder).  eae_adam_step_scaled
+ * multiplies the (summed) gradients by grad_scale = 1/world_size inside the optimizer kernel. */
+int eae_ae_grad_step_begin(eae_ctx* ctx, void* stream, const eae_step_io* io);
+int eae_ae_grad_step_end(eae_ctx* ctx, void* stream);
+void* eae_side_stream(eae_ctx* ctx);
+int eae_adam_step_scaled(eae_ctx* ctx, void* stream, float lr, float weight_decay, float grad_scale);
 /* eae_ae_grad_step + eae_adam_step: one iteration of the reference's batch loop (R.md:642-658). */
 int eae_ae_train_step(eae_ctx* ctx, void* stream, const eae_step_io* io, float lr);
 /* Encoder alone in the current mode (extract_features, R.md:2504: z = encoder(imgs)). */

@@ -184,7 +184,7 @@ def test_data_parallel_trainer_world1_rccl():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     created = False
     if not dist.is_initialized():
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        dist.init_process_group("nccl", rank=0, world_size=1)
         created = True
     try:
         x, y = gu.make_images(8, 100)
