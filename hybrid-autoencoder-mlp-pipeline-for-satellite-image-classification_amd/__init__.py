@@ -6,8 +6,9 @@ that restate its inline loops.  All arithmetic runs in hand-written gfx950 HIP k
 C ABI declared in ``include/eae.h``.
 """
 from .modules import Encoder, Decoder, SupervisedAutoencoder, MLP  # noqa: F401
+from .augment import augment_batch  # noqa: F401
 from .train import (fit_autoencoder, grid_search_autoencoder, extract_features, fit_mlp, grid_search_mlp,  # noqa: F401
                     evaluate)
 
 __all__ = ["Encoder", "Decoder", "SupervisedAutoencoder", "MLP", "fit_autoencoder", "grid_search_autoencoder",
-           "extract_features", "fit_mlp", "grid_search_mlp", "evaluate"]
+           "extract_features", "fit_mlp", "grid_search_mlp", "evaluate", "augment_batch"]

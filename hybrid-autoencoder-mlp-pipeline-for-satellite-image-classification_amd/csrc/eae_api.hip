@@ -768,6 +768,10 @@ extern "C" int eae_op_pack3x3(void* stream, const float* w, int A, int B, void* 
   hipFree(dev);
   return rc;
 }
+extern "C" int eae_augment(void* stream, const void* in_u8, float* out, int B, int H, int W, int train, float noise_std,
+                           unsigned long long seed, unsigned long long step, const int* params, const float* noise) {
+  return eae_launch_augment((hipStream_t)stream, in_u8, out, B, H, W, train, noise_std, seed, step, params, noise);
+}
 extern "C" int eae_op_adam(void* stream, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
                            double eps, double wd, long long step) {
   return eae_launch_adam((hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, wd, step);

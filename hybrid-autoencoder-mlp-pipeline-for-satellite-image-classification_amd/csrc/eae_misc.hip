@@ -275,3 +275,78 @@ int eae_launch_adam_scaled(hipStream_t st, float* p, const float* g, float* m, f
   EAE_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// On-device input staging: the reference's training transform (R.md:225-230)
+//   RandomHorizontalFlip -> RandomCrop(64, padding=4) -> ToTensor -> AddGaussianNoise(0, 0.03)   (eval: ToTensor only, R.md:232-234)
+// fused into one kernel: uint8 HWC [B,H,W,3] -> fp32 NCHW [B,3,H,W] (what conv1 reads), so a batch crosses PCIe as 12 KB/img.
+//   out[n,c,y,x] = img[n, y+top-4, flip ? W-1-(x+left-4) : x+left-4, c] / 255 (0 outside) + std * N(0,1)
+// Per-image (flip, top, left) and the noise come from a counter-based Philox4x32-10 stream keyed by (seed, step) unless
+// explicit `params` [B][3] / `noise` [B,3,H,W] are supplied (parity tests).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* o) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void augment_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                                                       int train, float std, unsigned long long seed, unsigned long long step,
+                                                       const int* __restrict__ params, const float* __restrict__ noise) {
+  const long plane = (long)H * W;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= plane * B) return;
+  const int n = (int)(p / plane), r = (int)(p % plane), y = r / W, x = r % W;
+  int flip = 0, top = 4, left = 4;
+  if (train) {
+    if (params) { flip = params[n * 3]; top = params[n * 3 + 1]; left = params[n * 3 + 2]; }
+    else {
+      uint32_t o[4];
+      philox4((uint32_t)n, 0x5eedu, (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+      flip = o[0] >> 31; top = (int)(((unsigned long long)o[1] * 9) >> 32); left = (int)(((unsigned long long)o[2] * 9) >> 32);
+    }
+  }
+  const int sy = y + top - 4;
+  int sx = x + left - 4;
+  const bool inside = sy >= 0 && sy < H && sx >= 0 && sx < W;
+  if (flip) sx = W - 1 - sx;
+  float v[3] = {0.f, 0.f, 0.f};
+  if (inside) {
+    const uint8_t* q = in + (((long)n * H + sy) * W + sx) * 3;
+    v[0] = q[0] / 255.0f; v[1] = q[1] / 255.0f; v[2] = q[2] / 255.0f;   // ToTensor: .div(255), exact
+  }
+  if (train && std != 0.f) {
+    if (noise) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = fmaf(std, noise[((long)n * 3 + c) * plane + r], v[c]);
+    } else {
+      uint32_t o[4];
+      philox4((uint32_t)p, (uint32_t)(p >> 32) ^ 0xA5A5u, (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed, ~(uint32_t)(seed >> 32), o);
+      // Box-Muller: two uniforms -> two normals (three needed: a second pair from o[2], o[3])
+      float u1 = ((o[0] >> 8) + 1) * (1.0f / 16777216.0f), u2 = (o[1] >> 8) * (1.0f / 16777216.0f);
+      float u3 = ((o[2] >> 8) + 1) * (1.0f / 16777216.0f), u4 = (o[3] >> 8) * (1.0f / 16777216.0f);
+      float r1 = sqrtf(-2.0f * __logf(u1)), r2 = sqrtf(-2.0f * __logf(u3));
+      v[0] = fmaf(std, r1 * __cosf(6.28318530718f * u2), v[0]);
+      v[1] = fmaf(std, r1 * __sinf(6.28318530718f * u2), v[1]);
+      v[2] = fmaf(std, r2 * __cosf(6.28318530718f * u4), v[2]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[((long)n * 3 + c) * plane + r] = v[c];
+}
+
+int eae_launch_augment(hipStream_t st, const void* in_u8, float* out, int B, int H, int W, int train, float std, unsigned long long seed,
+                       unsigned long long step, const int* params, const float* noise) {
+  if (!in_u8 || !out || B <= 0 || H <= 0 || W <= 0) return eae_set_error(-2, "augment: bad argument");
+  const long tot = (long)B * H * W;
+  hipLaunchKernelGGL(augment_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const uint8_t*)in_u8, out, B, H, W, train, std,
+                     seed, step, params, noise);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}

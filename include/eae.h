@@ -145,6 +145,14 @@ int eae_op_pack3x3(void* stream, const float* w, int A, int B, void* p1, void* p
 int eae_op_adam(void* stream, float* p, const float* g, float* m, float* v, long long n, double lr, double beta1,
                 double beta2, double eps, double weight_decay, long long step);
 
+/* ------------------------------------------------------------------ input staging ------ */
+/* The loader-side transforms of the reference fused on the device: train = RandomHorizontalFlip -> RandomCrop(H, padding=4)
+ * -> ToTensor -> AddGaussianNoise(0, noise_std) (R.md:211-230), eval = ToTensor (R.md:232-234).  in_u8: uint8 HWC [B,H,W,3];
+ * out: fp32 NCHW [B,3,H,W].  Randomness: Philox4x32-10 keyed by (seed, step) unless explicit per-image params int32 [B][3] =
+ * (flip, top, left) with top,left in 0..8 and/or standard-normal noise [B,3,H,W] are supplied. */
+int eae_augment(void* stream, const void* in_u8, float* out, int B, int H, int W, int train, float noise_std,
+                unsigned long long seed, unsigned long long step, const int* params, const float* noise);
+
 /* ------------------------------------------------------------------ external MLP (R.md:2549-2566) ---------- */
 typedef struct eae_mlp eae_mlp;
 #define EAE_MLP_NPARAMS 10

@@ -231,3 +231,21 @@ def test_torch_cpu_port(golden):
         x, y = gu.make_images(8, 200 + step)
         losses.append(T.train_step(p, opt, torch.from_numpy(x), torch.from_numpy(y), float(g["alpha"])))
     np.testing.assert_allclose(np.array(losses), g["losses"], rtol=1e-4)
+
+
+def test_augment_oracle_semantics():
+    """oracle/augment_numpy.py: flip happens before the pad-4 crop; (top,left)=(4,4) without flip is the identity; noise adds."""
+    from oracle.augment_numpy import augment_ref
+    rng = np.random.default_rng(0)
+    u8 = rng.integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)
+    ident = augment_ref(u8, [0, 0], [4, 4], [4, 4], None)
+    assert np.array_equal(ident, u8.transpose(0, 3, 1, 2).astype(np.float32) / np.float32(255))
+    out = augment_ref(u8, [1, 0], [0, 8], [0, 8], None)
+    # image 0: flipped, shifted down/right by 4 -> out[y,x] = img[y-4, 63-(x-4)]
+    assert out[0, 1, 10, 20] == np.float32(u8[0, 6, 63 - 16, 1]) / np.float32(255)
+    assert out[0, :, :4, :].max() == 0 and out[0, :, :, :4].max() == 0
+    # image 1: shifted up/left by 4 -> bottom/right borders are the zero padding
+    assert out[1, 2, 5, 7] == np.float32(u8[1, 9, 11, 2]) / np.float32(255)
+    assert out[1, :, 60:, :].max() == 0 and out[1, :, :, 60:].max() == 0
+    nz = rng.standard_normal((2, 3, 64, 64)).astype(np.float32)
+    np.testing.assert_allclose(augment_ref(u8, [0, 0], [4, 4], [4, 4], nz) - ident, 0.03 * nz, atol=1e-7)
