@@ -645,6 +645,13 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
     if (ent) ent->seen++;
   }
   c->adam_step += 1;
+  if (!ent) {      // plain eager step: Adam takes its bias-correction scalars by value (one launch less on the critical path)
+    int rc = forward_impl(c, st, io, true);
+    if (!rc) rc = backward_impl(c, st, io);
+    if (!rc) rc = eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f);
+    c->packed = false;
+    return rc;
+  }
   RC(eae_launch_set_dyn(st, c->dyn, lr, 0.9, 0.999, 0.0, c->adam_step));
   if (ent && ent->exec) {
     EAE_HIP(hipGraphLaunch(ent->exec, st));

@@ -265,18 +265,25 @@ __global__ __launch_bounds__(256, (CIN > 64 ? 1 : 2)) void igemm_s2_kernel(ConvA
     __syncthreads();
     EAE_STAMP(8 + chunk * 4 + 2);
     EAE_STAMP(8 + chunk * 4 + 3);
-    // ---- MFMAs: for every distinct patch offset, read the pixel fragments once and feed all taps that use it
+    // ---- MFMAs: for every distinct patch offset, read the pixel fragments once and feed all taps that use it.  The
+    //      fragments of offset o+1 are requested before the MFMAs of offset o (register double buffer), so the LDS latency
+    //      hides behind the matrix pipe even with a single wave per SIMD.
+    bf16x8 pf[2][MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+      pf[0][mi] = *reinterpret_cast<const bf16x8*>(patch + (pixb[mi] + G::off_delta(0)) * PIX_STRIDE + kgl * 8);
 #pragma unroll
     for (int o = 0; o < G::NOFF; ++o) {
-      bf16x8 pf[MT];
+      if (o + 1 < G::NOFF) {
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi)
-        pf[mi] = *reinterpret_cast<const bf16x8*>(patch + (pixb[mi] + G::off_delta(o)) * PIX_STRIDE + kgl * 8);
+        for (int mi = 0; mi < MT; ++mi)
+          pf[(o + 1) & 1][mi] = *reinterpret_cast<const bf16x8*>(patch + (pixb[mi] + G::off_delta(o + 1)) * PIX_STRIDE + kgl * 8);
+      }
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         if (G::tap_off(tap) != o) continue;
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) acc[G::tap_phase(tap)][mi] = mfma16(wf[tap], pf[mi], acc[G::tap_phase(tap)][mi]);
+        for (int mi = 0; mi < MT; ++mi) acc[G::tap_phase(tap)][mi] = mfma16(wf[tap], pf[o & 1][mi], acc[G::tap_phase(tap)][mi]);
       }
       if (chunk + 1 < NC) issue_slice(chunk + 1, o);
     }
