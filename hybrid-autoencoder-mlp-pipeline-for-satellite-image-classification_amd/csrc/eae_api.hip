@@ -434,7 +434,11 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
   if (io->z) EAE_HIP(hipMemcpyAsync(io->z, c->z, (size_t)B * c->L * 4, hipMemcpyDeviceToDevice, st));
   if (want_loss || want_grad) {
     const int n_ce = (head && io->labels) ? eae_head_blocks(B) : 0;
-    RC(eae_launch_loss_finalize(st, c->msepart, eae_edge_tiles(B, c->H, c->W), c->cepart, n_ce, io->alpha, numel, B,
+    // in a gradient step nothing on the main stream reads what this kernel writes (deconv4 bias gradient, loss scalars):
+    // it goes to the side stream, which backward_impl joins before the optimizer
+    hipStream_t ls = st;
+    if (want_grad) RC(fork_side(c, st, &ls));
+    RC(eae_launch_loss_finalize(ls, c->msepart, eae_edge_tiles(B, c->H, c->W), c->cepart, n_ce, io->alpha, numel, B,
                                 want_grad ? c->G + c->poff[33] : nullptr, io->loss_accum, io->loss_last));
   }
   return 0;
