@@ -41,15 +41,31 @@ struct ConvArgs {
 #ifdef EAE_STAMPS
 #define EAE_STAMP(i) do { if (a.dbg && (int)blockIdx.x == a.dbg_block && blockIdx.y == 0 && threadIdx.x == 0) { \
     unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); a.dbg[i] = t__; } } while (0)
+// start / end stamp (s_memrealtime: 100 MHz, one clock for the whole device) of EVERY workgroup (dbg[64 + 2*wg], +1) and the XCC/CU it ran on (dbg[64 + 2*8192 + wg])
+#define EAE_STAMP_WG(k) do { if (a.dbg && blockIdx.y == 0 && threadIdx.x == 0 && blockIdx.x < 8192) { \
+    unsigned long long t__; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); a.dbg[64 + 2 * blockIdx.x + (k)] = t__; \
+    if ((k) == 0) { unsigned id__; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id__)); unsigned xcc__; \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc__)); a.dbg[64 + 2 * 8192 + blockIdx.x] = ((unsigned long long)xcc__ << 32) | id__; } } } while (0)
 #else
 #define EAE_STAMP(i) do {} while (0)
+#define EAE_STAMP_WG(k) do {} while (0)
 #endif
 
 #ifndef EAE_LDS_SLACK
 #define EAE_LDS_SLACK 0
 #endif
 enum { KIND_CONV = 0, KIND_DECONV = 1 };
-constexpr int PIX_STRIDE = 40;       // bf16 elements per staged pixel: 32 channels + 8 pad (80 B) -> conflict-free reads
+constexpr int PIX_STRIDE = 40;       // edge / wgrad kernels: bf16 elements per staged pixel, 32 channels + 8 pad (80 B)
+// igemm patch: 2-D image [img][row][PWS pixels][32 ch], 64 B per pixel and no padding bytes (a 16x8 conv tile then fits
+// 4 workgroups per CU).  Inside every 256-byte group of 4 pixels of a row both the pixel slot and the 16-byte chunk are
+// XOR-ed with the group index, so the stride-2 fragment reads of the conv tiles are conflict-free (ds_read_b128 16-lane
+// groups {0-3,12-15,20-27},...; checked exhaustively per geometry, m-tile and tap: 16x8 and 8x8 conv 1.0-way, deconv 2-way as
+// with 80-byte padding).  Because the swizzle only depends on the column, a fragment address is
+//   (per-lane, per-kx base) + (compile-time row offset)  ->  the row part folds into the ds_read immediate offset.
+__device__ __forceinline__ int swz_col(int col, int kg) {     // element offset of (column, 8-channel group) inside a row
+  int r = col >> 2;
+  return ((col & ~3) | ((col ^ r) & 3)) * 32 + ((kg ^ r) & 3) * 8;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Epilogue helper: rows of a bf16 LDS tile [rows][BN+8] -> global with 16-byte stores, accumulating the per-channel
@@ -145,12 +161,20 @@ struct Geo {
   static constexpr int PH = (KIND == KIND_CONV) ? 2 * TH + 1 : TH + 1;
   static constexpr int PW = (KIND == KIND_CONV) ? 2 * TW + 1 : TW + 1;
   static constexpr int NPIX = NI * PH * PW;
+  static constexpr int PWS = (PW + 3) & ~3;                        // pixels of LDS space per patch row
+  static constexpr int RS = PWS * 32;                              // elements per patch row
+  static constexpr int MUL = (KIND == KIND_CONV) ? 2 : 1;          // patch pixels per tile position
+  static constexpr int NKX = (KIND == KIND_CONV) ? 3 : 2;          // distinct column offsets
+  static constexpr int RPM = (16 / TW) ? (16 / TW) : 1;            // tile rows per 16-position m-tile
   static constexpr int NPH = (KIND == KIND_CONV) ? 1 : 4;          // output phases
   static constexpr int NOFF = (KIND == KIND_CONV) ? 9 : 4;         // distinct patch offsets
   // patch pixel of position m for offset 0
-  __device__ static __forceinline__ int pixbase(int m) {
-    int img = m / (TH * TW), ty = (m / TW) % TH, tx = m % TW;
-    return (KIND == KIND_CONV) ? (img * PH + 2 * ty) * PW + 2 * tx : (img * PH + ty) * PW + tx;
+  // per-lane part: i = lane & 15 (position inside the m-tile), wbase = index of the wave's first m-tile, column offset kx
+  __device__ static __forceinline__ int frag_lane(int i, int wbase, int kx, int kg) {
+    int img, ty, tx = i % TW;
+    if (TH * TW <= 16) { img = wbase; ty = i / TW; }
+    else { int row = wbase * RPM + i / TW; img = row / TH; ty = row % TH; }
+    return (img * PH + MUL * ty) * RS + swz_col(MUL * tx + kx, kg);
   }
   // tap (ky,kx) -> patch offset id / phase.  deconv: oy = 2*iy - 1 + ky  =>  ky=1: (py=0, dy=0); ky=2: (py=1, dy=0); ky=0: (py=1, dy=1)
   __device__ static constexpr int tap_off(int tap) {
@@ -159,13 +183,22 @@ struct Geo {
   __device__ static constexpr int tap_phase(int tap) {
     return (KIND == KIND_CONV) ? 0 : ((tap / 3 != 1) ? 2 : 0) + ((tap % 3 != 1) ? 1 : 0);
   }
-  __device__ static constexpr int off_delta(int o) {     // patch pixel delta of offset id o
-    return (KIND == KIND_CONV) ? (o / 3) * PW + (o % 3) : (o >> 1) * PW + (o & 1);
+  __device__ static constexpr int off_row(int o) { return (KIND == KIND_CONV) ? o / 3 : o >> 1; }   // row / column of offset id o
+  __device__ static constexpr int off_col(int o) { return (KIND == KIND_CONV) ? o % 3 : o & 1; }
+  // compile-time part of a fragment address: m-tile mi (inside the wave's MT m-tiles), offset id o
+  __device__ static constexpr int frag_const(int mi, int o) {
+    return (TH * TW <= 16) ? (mi * PH + off_row(o)) * RS
+                           : (((mi * RPM) / TH) * PH + MUL * ((mi * RPM) % TH) + off_row(o)) * RS;
   }
 };
 
+// waves per SIMD the register allocation aims at (= workgroups per CU): the 32<->64-channel layers launch 1024 workgroups
+// at B=512, which only fit the 256 CUs in ONE round at 4 per CU (128 VGPRs, <= 40 KB LDS)
+// (the 64->32 transposed kind keeps 4 phases x 4 m-tiles of accumulators: 3 per CU is what fits without spilling)
+constexpr int ig_occ(int kind, int cin, int cout) { return cin > 64 ? 1 : (cin * cout > 2048 ? 2 : (kind == 0 ? 4 : 3)); }
+
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
-__global__ __launch_bounds__(256, (CIN > 64 ? 1 : 2)) void igemm_s2_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT)) void igemm_s2_kernel(ConvArgs a) {
   using G = Geo<KIND, TW, TH, NI>;
   static_assert(G::P == 64 || G::P == 128, "tile must hold 64 or 128 positions");
   static_assert(CIN % 32 == 0 && COUT % BN == 0 && (BN == 32 || BN == 64), "shape");
@@ -174,6 +207,8 @@ __global__ __launch_bounds__(256, (CIN > 64 ? 1 : 2)) void igemm_s2_kernel(ConvA
   constexpr int MT = (P / 16) / WM;                 // m-tiles (16 positions) per wave
   constexpr int NPA = (NPIX * 4 + 255) / 256;       // 16-byte patch pieces per thread
   constexpr int TS = BN + 8;
+  constexpr bool ROWSWEEP = (TW == 16 && NI == 1);      // m-tile == one tile row: sweep the patch rows (see the MFMA loop)
+  constexpr int PFB = ig_occ(KIND, CIN, COUT) >= 4 ? 1 : 2;   // pixel-fragment register buffers (double buffering costs 4*MT VGPRs)
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
   bf16_t* patch = smem;                             // [NPIX][PIX_STRIDE]; reused as the output tile [P][TS] + reduction scratch
 
@@ -190,16 +225,18 @@ __global__ __launch_bounds__(256, (CIN > 64 ? 1 : 2)) void igemm_s2_kernel(ConvA
   const int iy0 = (KIND == KIND_CONV) ? 2 * tyb * TH - 1 : tyb * TH, ix0 = (KIND == KIND_CONV) ? 2 * txb * TW - 1 : txb * TW;
 
   EAE_STAMP(0);
+  EAE_STAMP_WG(0);
   f32x4 acc[NPH][MT];
 #pragma unroll
   for (int i = 0; i < NPH; ++i)
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  int pixb[MT];
-#pragma unroll
-  for (int mi = 0; mi < MT; ++mi) pixb[mi] = G::pixbase((wm * MT + mi) * 16 + (lane & 15));
   const int kgl = lane >> 4;        // k-group of the lane inside an MFMA (8 channels)
+  static_assert(TH * TW <= 16 || (TH % (MT * G::RPM) == 0) || (WM == 1 && (MT * G::RPM) % TH == 0), "m-tile rows must not straddle images");
+  int lbase[G::NKX];                // swizzled fragment base of this lane per column offset; rows are immediate offsets
+#pragma unroll
+  for (int kx = 0; kx < G::NKX; ++kx) lbase[kx] = G::frag_lane(lane & 15, wm * MT, kx, kgl);
   const int kgs = tid & 3;          // k-group staged by this thread (256 % 4 == 0 -> fixed per thread)
   // this lane's weight-fragment row: output channel n0 + wn*16 + (lane&15), 8 input channels kgl*8..
   const bf16_t* wrow = a.wpack + (size_t)(n0 + wn * 16 + (lane & 15)) * 9 * CIN + kgl * 8;
@@ -211,6 +248,7 @@ __global__ __launch_bounds__(256, (CIN > 64 ? 1 : 2)) void igemm_s2_kernel(ConvA
   //      32-bit; out-of-image pieces use the hardware-checked out-of-range offset (no branches); both are chunk-independent.
   constexpr int NC = CIN / 32;
   uint32_t boff[NPA];
+  int loff[NPA];                    // LDS element offset of the piece
   bool val[NPA];
   {
     constexpr int DR = (64 / PW) % PH, DC = 64 % PW, DI = 64 / (PH * PW);
@@ -222,22 +260,21 @@ __global__ __launch_bounds__(256, (CIN > 64 ? 1 : 2)) void igemm_s2_kernel(ConvA
       int iy = iy0 + pr, ix = ix0 + pc, n = img0 + img;
       val[i] = (tid + i * 256 < NPIX * 4) && (n < a.B) && ((unsigned)iy < (unsigned)a.Hin) && ((unsigned)ix < (unsigned)a.Win);
       boff[i] = val[i] ? ((uint32_t)((n * a.Hin + iy) * a.Win + ix) * CIN + kgs * 8) * 2u : OOB_OFF;
+      loff[i] = (img * PH + pr) * G::RS + swz_col(pc, kgs);
       pc += DC; pr += DR; img += DI;
       if (pc >= PW) { pc -= PW; pr += 1; }
       if (pr >= PH) { pr -= PH; img += 1; }
     }
   }
-  // Software pipeline over the K-chunks (register double-buffering): the raw patch pieces and the 9 weight fragments of
-  // chunk c+1 are requested right after the barrier that publishes chunk c, so their latency hides behind the MFMA phase.
-  bf16x8 wnext[9];
+  // Software pipeline over the K-chunks: the raw patch pieces of chunk c+1 are requested in slices between the MFMA groups
+  // of chunk c (register double-buffering), so their latency hides behind the matrix pipe; the 9 weight fragments of chunk
+  // c+1 are requested right after chunk c's last MFMA (into the same registers) and arrive while the patch is being staged.
+  bf16x8 wf[9];
   RawPiece<SRC> raw[NPA];
   ChanCoef<SRC> cc;
   // prefetch requests are issued in NOFF slices, one after each offset's MFMA group, so that the vector-memory pipe
   // (the 64 B/clk L1 path is the scarce resource of the multi-chunk layers) drains while the matrix pipe works
   auto issue_slice = [&](int chunk, int o) {
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-      if (tap % G::NOFF == o) wnext[tap] = *reinterpret_cast<const bf16x8*>(wrow + tap * CIN + chunk * 32);
     if (o == 0) cc.load(a.src.coef, CIN, chunk * 32 + kgs * 8);
 #pragma unroll
     for (int i = 0; i < NPA; ++i)
@@ -247,6 +284,11 @@ __global__ __launch_bounds__(256, (CIN > 64 ? 1 : 2)) void igemm_s2_kernel(ConvA
 #pragma unroll
     for (int o = 0; o < G::NOFF; ++o) issue_slice(chunk, o);
   };
+  auto load_w = [&](int chunk) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) wf[tap] = *reinterpret_cast<const bf16x8*>(wrow + tap * CIN + chunk * 32);
+  };
+  load_w(0);
   issue(0);
 #pragma unroll
   for (int chunk = 0; chunk < NC; ++chunk) {
@@ -256,11 +298,8 @@ __global__ __launch_bounds__(256, (CIN > 64 ? 1 : 2)) void igemm_s2_kernel(ConvA
     for (int i = 0; i < NPA; ++i) {
       int q = tid + i * 256;
       if (q < NPIX * 4)
-        *reinterpret_cast<uint4*>(patch + (q >> 2) * PIX_STRIDE + kgs * 8) = transform_piece<SRC>(raw[i], val[i], cc);
+        *reinterpret_cast<uint4*>(patch + loff[i]) = transform_piece<SRC>(raw[i], val[i], cc);
     }
-    bf16x8 wf[9];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) wf[tap] = wnext[tap];
     EAE_STAMP(8 + chunk * 4 + 1);
     __syncthreads();
     EAE_STAMP(8 + chunk * 4 + 2);
@@ -268,26 +307,59 @@ __global__ __launch_bounds__(256, (CIN > 64 ? 1 : 2)) void igemm_s2_kernel(ConvA
     // ---- MFMAs: for every distinct patch offset, read the pixel fragments once and feed all taps that use it.  The
     //      fragments of offset o+1 are requested before the MFMAs of offset o (register double buffer), so the LDS latency
     //      hides behind the matrix pipe even with a single wave per SIMD.
-    bf16x8 pf[2][MT];
+    if constexpr (ROWSWEEP) {
+      // 16-wide tiles: an m-tile is one tile row, so the fragment of patch row R, column offset kx serves every (m-tile, ky)
+      // with MUL*mi + ky == R.  Sweeping the patch rows reads each fragment ONCE (conv: 51 instead of 72 ds_read_b128 per
+      // chunk, deconv: 18 instead of 32) and needs only 2 x NKX fragment registers (row R+1 is requested before row R's MFMAs).
+      constexpr int NROWS = G::MUL * MT + 1;
+      bf16x8 rf[2][G::NKX];
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-      pf[0][mi] = *reinterpret_cast<const bf16x8*>(patch + (pixb[mi] + G::off_delta(0)) * PIX_STRIDE + kgl * 8);
+      for (int kx = 0; kx < G::NKX; ++kx) rf[0][kx] = *reinterpret_cast<const bf16x8*>(patch + lbase[kx]);
 #pragma unroll
-    for (int o = 0; o < G::NOFF; ++o) {
-      if (o + 1 < G::NOFF) {
+      for (int R = 0; R < NROWS; ++R) {
+        if (R + 1 < NROWS) {
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-          pf[(o + 1) & 1][mi] = *reinterpret_cast<const bf16x8*>(patch + (pixb[mi] + G::off_delta(o + 1)) * PIX_STRIDE + kgl * 8);
+          for (int kx = 0; kx < G::NKX; ++kx) rf[(R + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(patch + lbase[kx] + (R + 1) * G::RS);
+        }
+#pragma unroll
+        for (int cx = 0; cx < G::NKX; ++cx)
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            constexpr int dummy = 0; (void)dummy;
+            const int o = G::tap_off(tap), ry = G::off_row(o);
+            if (G::off_col(o) != cx || R < ry || (R - ry) % G::MUL != 0 || (R - ry) / G::MUL >= MT) continue;
+            const int mi = (R - ry) / G::MUL;
+            acc[G::tap_phase(tap)][mi] = mfma16(wf[tap], rf[R & 1][cx], acc[G::tap_phase(tap)][mi]);
+          }
+        if (chunk + 1 < NC && R < G::NOFF) issue_slice(chunk + 1, R);
       }
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        if (G::tap_off(tap) != o) continue;
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) acc[G::tap_phase(tap)][mi] = mfma16(wf[tap], pf[o & 1][mi], acc[G::tap_phase(tap)][mi]);
+    } else {
+    bf16x8 pf[PFB][MT];
+  #pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+        pf[0][mi] = *reinterpret_cast<const bf16x8*>(patch + lbase[G::off_col(0)] + G::frag_const(mi, 0));
+  #pragma unroll
+      for (int o = 0; o < G::NOFF; ++o) {
+        if (PFB == 2 && o + 1 < G::NOFF) {
+  #pragma unroll
+          for (int mi = 0; mi < MT; ++mi)
+            pf[(o + 1) % PFB][mi] = *reinterpret_cast<const bf16x8*>(patch + lbase[G::off_col(o + 1)] + G::frag_const(mi, o + 1));
+        }
+  #pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          if (G::tap_off(tap) != o) continue;
+  #pragma unroll
+          for (int mi = 0; mi < MT; ++mi) acc[G::tap_phase(tap)][mi] = mfma16(wf[tap], pf[o % PFB][mi], acc[G::tap_phase(tap)][mi]);
+        }
+        if (PFB == 1 && o + 1 < G::NOFF) {
+  #pragma unroll
+          for (int mi = 0; mi < MT; ++mi)
+            pf[0][mi] = *reinterpret_cast<const bf16x8*>(patch + lbase[G::off_col(o + 1)] + G::frag_const(mi, o + 1));
+        }
+        if (chunk + 1 < NC) issue_slice(chunk + 1, o);
       }
-      if (chunk + 1 < NC) issue_slice(chunk + 1, o);
     }
-    if (chunk + 1 < NC) __syncthreads();
+    if (chunk + 1 < NC) { load_w(chunk + 1); __syncthreads(); }
   }
   // ---- epilogue: per phase, accumulators (lane = pixel, 4 consecutive channels in regs) -> LDS tile -> global
   EAE_STAMP(4);
@@ -360,12 +432,13 @@ __global__ __launch_bounds__(256, (CIN > 64 ? 1 : 2)) void igemm_s2_kernel(ConvA
   }
   epi.end(a, red, n0, blockIdx.x);
   EAE_STAMP(7);
+  EAE_STAMP_WG(1);
 }
 
 template <int KIND, int BN, int TW, int TH, int NI>
 constexpr size_t igemm_smem() {
   using G = Geo<KIND, TW, TH, NI>;
-  constexpr size_t patch = (size_t)G::NPIX * PIX_STRIDE * 2;
+  constexpr size_t patch = (size_t)NI * G::PH * G::RS * 2;
   constexpr size_t tile = (size_t)G::P * (BN + 8) * 2 + (size_t)2 * (256 / (BN / 8)) * BN * 4;
   return (patch > tile ? patch : tile) + EAE_LDS_SLACK;
 }
