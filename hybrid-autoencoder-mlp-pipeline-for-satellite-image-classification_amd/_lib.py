@@ -60,6 +60,12 @@ _PROTOS = {
     "eae_op_bn_eval_coef": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_float, vp]),
     "eae_op_bn_bwd_finalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_longlong, vp, vp, vp, vp, vp]),
     "eae_op_pack3x3": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+    "eae_op_fc_splitk": (C.c_int, [vp, EaeSrc, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_longlong, vp]),
+    "eae_op_fc_bias_bf16": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "eae_op_fc_wgrad": (C.c_int, [vp, C.c_int, EaeSrc, EaeSrc, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "eae_op_head_scratch_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "eae_op_head_ce": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_longlong]),
+    "eae_op_sigmoid_bwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "eae_augment": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_ulonglong, C.c_ulonglong, vp, vp]),
     "eae_op_adam": (C.c_int, [vp, vp, vp, vp, vp, C.c_longlong, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_longlong]),
     "eae_mlp_layout": (C.c_int, [C.c_int, C.c_int, c_ll_p, c_ll_p]),

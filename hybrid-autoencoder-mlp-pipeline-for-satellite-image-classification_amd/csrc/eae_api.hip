@@ -765,6 +765,60 @@ extern "C" int eae_op_bn_bwd_finalize(void* stream, const float* stat_part, int 
                                       const float* coef_fwd, float* dgamma, float* dbeta, float* coef_bwd) {
   return eae_launch_bn_bwd_finalize((hipStream_t)stream, stat_part, ntiles, C, count, gamma, coef_fwd, dgamma, dbeta, coef_bwd);
 }
+extern "C" int eae_op_fc_splitk(void* stream, eae_src a, const void* w, int M, int N, int K, const float* bias, const float* addend,
+                                float* scratch, long long scratch_floats, float* out) {
+  if (a.mode != SRC_RAW && a.mode != SRC_BNRELU) return eae_set_error(EAE_ERR_ARG, "fc_splitk: source mode must be 0 or 1");
+  if (K % 128 || (long long)(K / 128) * M * N > scratch_floats) return eae_set_error(EAE_ERR_ARG, "fc_splitk: K % 128 != 0 or scratch too small");
+  FcNtArgs f = FcNtArgs();
+  f.a = to_src(a); f.w = (const bf16_t*)w; f.M = M; f.N = N; f.K = K; f.klen = 128; f.part = scratch;
+  RC(eae_launch_fc_nt((hipStream_t)stream, f, a.mode, FCE_PARTIAL, K / 128));
+  return eae_launch_fc_reduce((hipStream_t)stream, scratch, K / 128, M, N, bias, addend, nullptr, out);
+}
+extern "C" int eae_op_fc_bias_bf16(void* stream, const float* a_f32, const void* w, int M, int N, int K, const float* bias, void* out) {
+  FcNtArgs f = FcNtArgs();
+  f.a = src_f32(a_f32); f.w = (const bf16_t*)w; f.M = M; f.N = N; f.K = K; f.klen = K;
+  f.c = ConvArgs(); f.c.out = (bf16_t*)out; f.c.bias = bias;
+  return eae_launch_fc_nt((hipStream_t)stream, f, SRC_F32, FCE_BIAS_BF16, 1);
+}
+extern "C" int eae_op_fc_wgrad(void* stream, int mode, eae_src p, eae_src q, int Bt, int I, int J, int Pn, float* dw, float* colsum) {
+  FcTnArgs t = FcTnArgs();
+  t.p = to_src(p); t.q = to_src(q); t.Bt = Bt; t.I = I; t.J = J; t.out = dw; t.colsum = colsum; t.out_mode = mode; t.Pn = Pn;
+  if (mode == 0) return eae_launch_fc_tn((hipStream_t)stream, t, SRC_RAW, SRC_F32);
+  if (mode == 1) return eae_launch_fc_tn((hipStream_t)stream, t, SRC_F32, SRC_BNRELU);
+  return eae_set_error(EAE_ERR_ARG, "fc_wgrad: mode must be 0 (dec.fc) or 1 (enc.fc)");
+}
+static long long head_stride_of(int L, int C) { return r4(128LL * L) + 128 + r4(128LL * C) + r4(C); }
+extern "C" long long eae_op_head_scratch_floats(int B, int L, int C) {
+  return (long long)eae_head_blocks(B) * (head_stride_of(L, C) + 2) + 64;
+}
+extern "C" int eae_op_head_ce(void* stream, const float* z, const float* w1, const float* b1, const float* w2, const float* b2,
+                              const long long* labels, int B, int L, int C, float* logits, float* dz, float* grads, float* loss2,
+                              float* scratch, long long scratch_floats) {
+  if (!z || !w1 || !b1 || !w2 || !b2 || !scratch) return eae_set_error(EAE_ERR_ARG, "head_ce: NULL argument");
+  if (scratch_floats < eae_op_head_scratch_floats(B, L, C)) return eae_set_error(EAE_ERR_ARG, "head_ce: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  const long long stride = head_stride_of(L, C);
+  const int nb = eae_head_blocks(B);
+  float* ce_part = scratch;                         // [nb][2]
+  float* gpart = scratch + (((long long)nb * 2 + 3) & ~3LL);
+  HeadArgs h = HeadArgs();
+  h.z = z; h.w1 = w1; h.b1 = b1; h.w2 = w2; h.b2 = b2; h.labels = labels; h.B = B; h.L = L; h.C = C; h.inv_batch = 1.0f / (float)B;
+  h.logits = logits; h.dz = dz; h.grad_part = (labels && grads) ? gpart : nullptr; h.grad_stride = stride; h.loss_part = ce_part;
+  RC(eae_launch_head(st, h));
+  if (labels && grads) {
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(stride / 4)), dim3(256), 0, st, gpart, nb, (long)(stride / 4), grads, 1.0f);
+    EAE_LAUNCH_CHECK();
+  }
+  if (labels && loss2) RC(eae_launch_ce_mean(st, ce_part, nb, B, loss2));
+  return 0;
+}
+extern "C" int eae_op_sigmoid_bwd(void* stream, const float* x_hat, const float* dx_hat, int B, int H, int W, void* g4, float* db,
+                                  float* scratch) {
+  hipStream_t st = (hipStream_t)stream;
+  RC(eae_launch_sigmoid_bwd(st, x_hat, dx_hat, g4, scratch, B, H, W));
+  const int nblk = (int)(((long long)B * H * W + 255) / 256);
+  return eae_launch_loss_finalize(st, scratch, nblk, nullptr, 0, 0.f, 1.0, B, db, nullptr, nullptr);
+}
 extern "C" int eae_op_pack3x3(void* stream, const float* w, int A, int B, void* p1, void* p2) {
   // one-off helper for tests: builds a 2-entry descriptor table on the fly (synchronous upload)
   PackDesc d[2];

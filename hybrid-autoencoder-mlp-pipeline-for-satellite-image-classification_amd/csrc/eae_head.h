@@ -16,5 +16,6 @@ struct HeadArgs {
 };
 int eae_launch_head(hipStream_t st, const HeadArgs& a);
 int eae_head_blocks(int B);
+int eae_launch_ce_mean(hipStream_t st, const float* ce_part, int n, int B, float* out2);
 int eae_launch_loss_finalize(hipStream_t st, const float* mse_part, int n_mse, const float* ce_part, int n_ce, float alpha,
                              double numel, int B, float* db4, float* accum, float* last);

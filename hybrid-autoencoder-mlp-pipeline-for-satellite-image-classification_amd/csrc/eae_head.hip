@@ -182,4 +182,17 @@ int eae_launch_loss_finalize(hipStream_t st, const float* mse_part, int n_mse, c
   return 0;
 }
 
+// op-level helper: out2[0] = mean CE over the batch, out2[1] = number of correct argmax (fixed-order sum of the block partials)
+__global__ void ce_mean_kernel(const float* ce_part, int n, float B, float* out2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0, c = 0.0;
+  for (int i = 0; i < n; ++i) { s += ce_part[2 * i]; c += ce_part[2 * i + 1]; }
+  out2[0] = (float)(s / B); out2[1] = (float)c;
+}
+int eae_launch_ce_mean(hipStream_t st, const float* ce_part, int n, int B, float* out2) {
+  hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(64), 0, st, ce_part, n, (float)B, out2);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+
 int eae_head_blocks(int B) { return (B + HR - 1) / HR; }

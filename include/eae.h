@@ -118,7 +118,7 @@ typedef struct eae_src {
 
 /* kind 0: 3x3 stride-2 pad-1 conv (aten::convolution of nn.Conv2d, R.md:292-304);
  * kind 1: 3x3 stride-2 pad-1 output_padding-1 transposed conv (nn.ConvTranspose2d, R.md:370-378).
- * wpack: bf16 [cout][9][cin].  epilogue 0: +bias, raw bf16 out, statistics partials [ntiles][2][cout];
+ * wpack: bf16 [cout][9][cin].  epilogue 0: +bias, raw bf16 out, statistics partials [2][cout][ntiles] (channel-major);
  * 1: ReLU mask of (yprev, prev_coef) + BN-backward partials; 2: plain store. */
 int eae_op_conv_s2(void* stream, int kind, eae_src src, int cin, int cout, int B, int Hin, int Win, const void* wpack,
                    const float* bias, void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef);
@@ -140,6 +140,31 @@ int eae_op_bn_eval_coef(void* stream, int C, const float* gamma, const float* be
                         const float* running_var, float eps, float* coef);
 int eae_op_bn_bwd_finalize(void* stream, const float* stat_part, int ntiles, int C, long long count, const float* gamma,
                            const float* coef_fwd, float* dgamma, float* dbeta, float* coef_bwd);
+/* Latent projections (nn.Linear(256*h*w, L) R.md:309 and nn.Linear(L, 256*h*w) R.md:365) on NHWC-flattened activations
+ * (feature index k' = pixel*256 + channel; the permutation to the reference's c*P+p order lives in the packed weights).
+ *   eae_op_fc_splitk : out[M][N] fp32 = T(a)[M][K] . w[N][K]^T (+ bias[N]) (+ addend[M][N]); split-K in slices of 128 through
+ *                      `scratch` (>= K/128 * M * N floats) and a fixed-order reduction.  a.mode 0 (bf16) or 1 (BN+ReLU on load,
+ *                      coef [4][256], channel = k % 256).  N % 64 == 0, K % 128 == 0.      (enc.fc forward, dec.fc backward-data)
+ *   eae_op_fc_bias_bf16 : out[M][N] bf16 = a_f32[M][K] . w[N][K]^T + bias[N]; N % 256 == 0, K % 64 == 0.   (dec.fc forward)
+ *   eae_op_fc_wgrad : dw = P^T . Q over the batch, written in the REFERENCE weight layout; mode 0: P = bf16 [Bt][I], Q = fp32
+ *                     [Bt][J], dw [I][J] with rows permuted back to c*Pn+p (dec.fc); mode 1: P = fp32 [Bt][I], Q = BN+ReLU source
+ *                     [Bt][J], dw [I][J] with columns permuted back (enc.fc); colsum = sum_b P (bias gradient) or NULL. */
+int eae_op_fc_splitk(void* stream, eae_src a, const void* w_bf16, int M, int N, int K, const float* bias, const float* addend,
+                     float* scratch, long long scratch_floats, float* out);
+int eae_op_fc_bias_bf16(void* stream, const float* a_f32, const void* w_bf16, int M, int N, int K, const float* bias, void* out_bf16);
+int eae_op_fc_wgrad(void* stream, int mode, eae_src p, eae_src q, int Bt, int I, int J, int Pn, float* dw, float* colsum);
+/* Classification head Linear(L,128)-ReLU-Linear(128,C) (R.md:423-427) fused with CrossEntropyLoss(mean) (R.md:623) and its
+ * whole backward, fp32.  grads = the 4 head gradients in state-dict order (W1 [128][L], b1 [128], W2 [C][128], b2 [C], each
+ * padded to a multiple of 4 floats); loss2[0] = mean CE, loss2[1] = number of correct argmax.  labels NULL: forward only.
+ * scratch >= eae_op_head_scratch_floats(B, L, C). */
+long long eae_op_head_scratch_floats(int B, int L, int C);
+int eae_op_head_ce(void* stream, const float* z, const float* w1, const float* b1, const float* w2, const float* b2,
+                   const long long* labels, int B, int L, int C, float* logits, float* dz, float* grads, float* loss2,
+                   float* scratch, long long scratch_floats);
+/* Sigmoid backward for an externally supplied dL/dx_hat (autograd path): g4 = bf16 NHWC4 of dx_hat*x_hat*(1-x_hat), plus the
+ * deconv4 bias gradient db[3]; x_hat, dx_hat fp32 NCHW [B,3,H,W]; scratch >= ceil(B*H*W/256)*4 floats. */
+int eae_op_sigmoid_bwd(void* stream, const float* x_hat, const float* dx_hat, int B, int H, int W, void* g4, float* db,
+                       float* scratch);
 /* pack a [A][B][3][3] fp32 weight into bf16 p1 [A][9][B] and p2 [B][9][A] */
 int eae_op_pack3x3(void* stream, const float* w, int A, int B, void* p1, void* p2);
 int eae_op_adam(void* stream, float* p, const float* g, float* m, float* v, long long n, double lr, double beta1,

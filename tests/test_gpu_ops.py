@@ -179,3 +179,120 @@ def test_augment_matches_oracle(lib):
     clean = augment_batch(big, train=True, seed=3, step=5, noise_std=0.0)
     resid = (a - clean).cpu().numpy()
     assert abs(resid.std() - 0.03) < 5e-4 and abs(resid.mean()) < 2e-4
+
+
+def _nhwc_perm_rows(w_ref_KL, Pn):
+    """reference dec.fc weight [K][L] with K = c*Pn + p  ->  packed rows k' = p*256 + c"""
+    K, L = w_ref_KL.shape
+    return w_ref_KL.reshape(256, Pn, L).transpose(1, 0, 2).reshape(K, L)
+
+
+def test_fc_ops(lib):
+    """enc.fc forward (split-K, BN+ReLU source), dec.fc forward (bias, bf16 out) and both weight gradients (R.md:309, 365)."""
+    import gpu_util as G
+    from eae_amd._lib import check
+    rng = np.random.default_rng(11)
+    B, L, Pn = 37, 64, 16
+    K = 256 * Pn
+    # ---- enc.fc forward: z = relu(s*y4+t) (NHWC-flattened) . We^T + b
+    y4 = O.bf16_round(rng.standard_normal((B, 256, 4, 4)).astype(np.float32))
+    s = (1.0 + 0.1 * rng.standard_normal(256)).astype(np.float32); t = (0.1 * rng.standard_normal(256)).astype(np.float32)
+    coef = np.stack([s, t, np.zeros(256, np.float32), np.ones(256, np.float32)])
+    act = O.bf16_round(np.maximum(y4 * s[None, :, None, None] + t[None, :, None, None], 0.0))        # what the kernel feeds the MFMA
+    we = O.bf16_round((rng.standard_normal((L, K)) * 0.02).astype(np.float32))                        # reference layout [L][c*Pn+p]
+    be = rng.standard_normal(L).astype(np.float32)
+    we_pack = we.reshape(L, 256, Pn).transpose(0, 2, 1).reshape(L, K)                                 # k' = p*256 + c
+    y4d = G.to_nhwc_bf16(y4); coefd = G.f32(coef); wed = G.f32(we_pack).to(torch.bfloat16); bed = G.f32(be)
+    scratch = torch.empty((K // 128) * B * L + 1024, dtype=torch.float32, device=G.dev())
+    z = torch.empty((B, L), dtype=torch.float32, device=G.dev())
+    check(lib.eae_op_fc_splitk(G.stream(), G.src(1, y4d, None, coefd), G.ptr(wed), B, L, K, G.ptr(bed), None, G.ptr(scratch), scratch.numel(), G.ptr(z)))
+    torch.cuda.synchronize()
+    ref = O.linear_fwd(act.reshape(B, K).astype(np.float64), we.astype(np.float64), be)
+    assert G.relmax(z.cpu().numpy(), ref) < 2e-3        # the kernel's BN+ReLU is fp32 then bf16: up to 1 ulp per operand vs the rounded oracle input
+    # ---- dec.fc forward: d0 (NHWC bf16) = z . Wd^T + bd
+    zz = rng.standard_normal((B, L)).astype(np.float32)
+    wd = O.bf16_round((rng.standard_normal((K, L)) * 0.1).astype(np.float32))                         # reference [K][L], K = c*Pn+p
+    bd = rng.standard_normal(K).astype(np.float32)
+    wdd = G.f32(_nhwc_perm_rows(wd, Pn)).to(torch.bfloat16)
+    bdd = G.f32(bd.reshape(256, Pn).T.reshape(K))
+    zd = G.f32(zz)
+    d0 = torch.empty((B, K), dtype=torch.bfloat16, device=G.dev())
+    check(lib.eae_op_fc_bias_bf16(G.stream(), G.ptr(zd), G.ptr(wdd), B, K, L, G.ptr(bdd), G.ptr(d0)))
+    torch.cuda.synchronize()
+    ref_d0 = O.linear_fwd(O.bf16_round(zz).astype(np.float64), wd.astype(np.float64), bd)           # [B][c*Pn+p]
+    got_d0 = d0.float().cpu().numpy().reshape(B, Pn, 256).transpose(0, 2, 1).reshape(B, K)
+    assert np.abs(got_d0 - ref_d0).max() <= 2 ** -7 * np.abs(ref_d0).max() + 1e-3
+    # ---- dec.fc weight gradient (mode 0): dW[K][L] = g^T . z, db = sum g
+    g = O.bf16_round(rng.standard_normal((B, 256, 4, 4)).astype(np.float32))
+    gd = G.to_nhwc_bf16(g)
+    dw = torch.zeros((K, L), dtype=torch.float32, device=G.dev()); db = torch.zeros(K, dtype=torch.float32, device=G.dev())
+    check(lib.eae_op_fc_wgrad(G.stream(), 0, G.src(0, gd), G.src(3, zd), B, K, L, Pn, G.ptr(dw), G.ptr(db)))
+    torch.cuda.synchronize()
+    _, refw, refb = O.linear_bwd(O.bf16_round(zz).astype(np.float64), wd.astype(np.float64), g.reshape(B, K).astype(np.float64))
+    assert G.relmax(dw.cpu().numpy(), refw) < 1e-4 and G.relmax(db.cpu().numpy(), refb) < 1e-4
+    # ---- enc.fc weight gradient (mode 1): dW[L][K] = dz^T . act, db = sum dz
+    dz = rng.standard_normal((B, L)).astype(np.float32)
+    dzd = G.f32(dz)
+    dwe = torch.zeros((L, K), dtype=torch.float32, device=G.dev()); dbe = torch.zeros(L, dtype=torch.float32, device=G.dev())
+    check(lib.eae_op_fc_wgrad(G.stream(), 1, G.src(3, dzd), G.src(1, y4d, None, coefd), B, L, K, Pn, G.ptr(dwe), G.ptr(dbe)))
+    torch.cuda.synchronize()
+    _, refwe, refbe = O.linear_bwd(act.reshape(B, K).astype(np.float64), we.astype(np.float64), O.bf16_round(dz).astype(np.float64))
+    assert G.relmax(dwe.cpu().numpy(), refwe) < 3e-3 and G.relmax(dbe.cpu().numpy(), refbe) < 1e-2
+
+
+def test_head_ce_op(lib):
+    """Linear(L,128)-ReLU-Linear(128,C) + CrossEntropy(mean) forward/backward in fp32 (R.md:423-427, 623) vs the oracle."""
+    import gpu_util as G
+    from eae_amd._lib import check
+    rng = np.random.default_rng(12)
+    for B, L, C in ((21, 64, 10), (64, 128, 10)):
+        z = rng.standard_normal((B, L)).astype(np.float32)
+        w1 = (rng.standard_normal((128, L)) * 0.2).astype(np.float32); b1 = (rng.standard_normal(128) * 0.1).astype(np.float32)
+        w2 = (rng.standard_normal((C, 128)) * 0.2).astype(np.float32); b2 = (rng.standard_normal(C) * 0.1).astype(np.float32)
+        labels = rng.integers(0, C, B).astype(np.int64)
+        d = [G.f32(a) for a in (z, w1, b1, w2, b2)]
+        lab = torch.from_numpy(labels).to(G.dev())
+        nsc = lib.eae_op_head_scratch_floats(B, L, C)
+        scratch = torch.zeros(nsc, dtype=torch.float32, device=G.dev())
+        logits = torch.empty((B, C), dtype=torch.float32, device=G.dev()); dz = torch.empty((B, L), dtype=torch.float32, device=G.dev())
+        r4 = lambda n: (n + 3) // 4 * 4
+        grads = torch.zeros(r4(128 * L) + 128 + r4(128 * C) + r4(C), dtype=torch.float32, device=G.dev())
+        loss2 = torch.zeros(2, dtype=torch.float32, device=G.dev())
+        check(lib.eae_op_head_ce(G.stream(), *[G.ptr(t) for t in d], G.ptr(lab), B, L, C, G.ptr(logits), G.ptr(dz), G.ptr(grads), G.ptr(loss2),
+                                 G.ptr(scratch), nsc))
+        torch.cuda.synchronize()
+        h = np.maximum(O.linear_fwd(z.astype(np.float64), w1.astype(np.float64), b1), 0.0)
+        lg = O.linear_fwd(h, w2.astype(np.float64), b2)
+        loss, dl = O.cross_entropy(lg, labels)
+        dh, dw2, db2 = O.linear_bwd(h, w2.astype(np.float64), dl.astype(np.float64))
+        dh = dh * (h > 0)
+        dzr, dw1, db1 = O.linear_bwd(z.astype(np.float64), w1.astype(np.float64), dh)
+        np.testing.assert_allclose(logits.cpu().numpy(), lg, rtol=1e-4, atol=1e-4)
+        l2 = loss2.cpu().numpy()
+        assert abs(l2[0] - loss) < 1e-4 and l2[1] == float((lg.argmax(1) == labels).sum())
+        np.testing.assert_allclose(dz.cpu().numpy(), dzr, rtol=1e-3, atol=1e-6)
+        gr = grads.cpu().numpy()
+        o = 0
+        for ref in (dw1, db1, dw2, db2):
+            n = ref.size
+            np.testing.assert_allclose(gr[o:o + n].reshape(ref.shape), ref, rtol=1e-3, atol=1e-6)
+            o += r4(n)
+
+
+def test_sigmoid_bwd_op(lib):
+    import gpu_util as G
+    from eae_amd._lib import check
+    rng = np.random.default_rng(13)
+    B = 2
+    xh = rng.random((B, 3, 64, 64)).astype(np.float32) * 0.98 + 0.01
+    dxh = rng.standard_normal((B, 3, 64, 64)).astype(np.float32)
+    g4 = torch.zeros((B, 64, 64, 4), dtype=torch.bfloat16, device=G.dev())
+    db = torch.zeros(4, dtype=torch.float32, device=G.dev())
+    scratch = torch.zeros((B * 64 * 64 + 255) // 256 * 4 + 16, dtype=torch.float32, device=G.dev())
+    xhd, dxhd = G.f32(xh), G.f32(dxh)
+    check(lib.eae_op_sigmoid_bwd(G.stream(), G.ptr(xhd), G.ptr(dxhd), B, 64, 64, G.ptr(g4), G.ptr(db), G.ptr(scratch)))
+    torch.cuda.synchronize()
+    ref = dxh * xh * (1.0 - xh)
+    got = g4.float().cpu().numpy()[..., :3].transpose(0, 3, 1, 2)
+    assert np.abs(got - ref).max() <= 2 ** -8 * np.abs(ref).max() + 1e-6
+    np.testing.assert_allclose(db.cpu().numpy()[:3], O.bf16_round(ref).sum((0, 2, 3)), rtol=2e-3, atol=1e-3)
