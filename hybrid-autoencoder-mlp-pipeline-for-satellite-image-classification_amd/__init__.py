@@ -9,6 +9,9 @@ from .modules import Encoder, Decoder, SupervisedAutoencoder, MLP  # noqa: F401
 from .augment import augment_batch  # noqa: F401
 from .train import (fit_autoencoder, grid_search_autoencoder, extract_features, fit_mlp, grid_search_mlp,  # noqa: F401
                     evaluate)
+from .report import confusion_matrix, classification_report, loss_heatmap  # noqa: F401
+from .probe import ce_mse_ratio_probe  # noqa: F401
 
 __all__ = ["Encoder", "Decoder", "SupervisedAutoencoder", "MLP", "fit_autoencoder", "grid_search_autoencoder",
-           "extract_features", "fit_mlp", "grid_search_mlp", "evaluate", "augment_batch"]
+           "extract_features", "fit_mlp", "grid_search_mlp", "evaluate", "augment_batch",
+           "confusion_matrix", "classification_report", "loss_heatmap", "ce_mse_ratio_probe"]

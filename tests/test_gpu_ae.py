@@ -261,3 +261,25 @@ def test_graph_replay_equals_eager():
     assert np.array_equal(res[0][2], res[1][2]), (res[0][2], res[1][2])
     assert res[0][3] == res[1][3] == 7
     assert np.isfinite(res[0][0]).all()
+
+
+def test_ce_mse_ratio_probe_vs_oracle():
+    """R.md:501-519: fresh latent-128 models, train-mode forward under no_grad, ratio CE/MSE; each trial's parameters are
+    captured and replayed through the bf16-emulating oracle.  BN running statistics must have been updated (Appendix A.9)."""
+    import eae_amd
+    x, y = gu.make_images(16, 321)
+    states = []
+
+    def grab(i, model):
+        states.append({k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
+
+    torch.manual_seed(77)
+    ratios = eae_amd.ce_mse_ratio_probe([(torch.from_numpy(x), torch.from_numpy(y))], n_models=3, on_model=grab)
+    assert len(ratios) == 3 and len(states) == 3
+    assert not np.array_equal(states[0]["enc.encoder.0.weight"], states[1]["enc.encoder.0.weight"])       # re-drawn every trial
+    assert int(states[1]["enc.encoder.1.num_batches_tracked"]) == 0                                     # and BN buffers reset
+    for r, sd in zip(ratios, states):
+        out = O.ae_forward(sd, x, train=True, quant="bf16")
+        _, l_r, l_c = O.ae_loss(out, x, y, 1.0)
+        assert abs(r - float(l_c) / float(l_r)) <= 1e-2 * float(l_c) / float(l_r), (r, l_c, l_r)
+        assert 5.0 < r < 100.0           # the reference's histogram sits around 25-38 for real images (R.md:532)
