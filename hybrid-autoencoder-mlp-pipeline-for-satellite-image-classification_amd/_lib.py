@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libeae.so")
+LIB_PATH = os.environ.get("EAE_LIB_PATH") or os.path.join(HERE, "libeae.so")     # EAE_LIB_PATH: diagnostic build variants
 
 c_float_p = C.POINTER(C.c_float)
 c_ll_p = C.POINTER(C.c_longlong)
@@ -50,6 +50,7 @@ _PROTOS = {
     "eae_debug_copy": (C.c_int, [vp, C.c_int, vp, C.c_longlong]),
     "eae_profile_enable": (C.c_int, [vp, C.c_int]),
     "eae_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), c_ll_p]),
+    "eae_profile_read2": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), c_ll_p]),
     "eae_op_conv_s2": (C.c_int, [vp, C.c_int, EaeSrc, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]),
     "eae_op_conv_s2_ntiles": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "eae_op_edge_conv": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]),

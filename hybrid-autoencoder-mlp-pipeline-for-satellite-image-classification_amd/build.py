@@ -62,5 +62,44 @@ def build(verbose=True, force=False):
     return LIB
 
 
+def device_code_objects(lib=LIB):
+    """The gfx950 code objects embedded in the library (clang offload bundles of the .hip_fatbin section), as bytes."""
+    import re
+    import struct
+    d = open(lib, "rb").read()
+    out = []
+    for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", d):
+        p = m.start()
+        n = struct.unpack_from("<Q", d, p + 24)[0]
+        o = p + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", d, o)
+            o += 24
+            triple = d[o:o + tl].decode(errors="replace")
+            o += tl
+            if "gfx950" in triple and size:
+                out.append(d[p + off:p + off + size])
+    return out
+
+
+def scan_packed_fp32(lib=LIB, objdump="/opt/rocm/lib/llvm/bin/llvm-objdump"):
+    """(number of v_pk_*_f32 instructions, those carrying an `op_sel:` modifier) in the library's device code.
+    The second number must be 0: on gfx950 / ROCm 7.2 that form returned wrong low-lane results in lanes 48-63 whenever an
+    MFMA kernel shared the SIMD (tools/race_mixed.py is the A/B reproducer)."""
+    import re
+    import tempfile
+    total = opsel = 0
+    for co in device_code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".o") as f:
+            f.write(co)
+            f.flush()
+            r = subprocess.run([objdump, "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True)
+        for line in r.stdout.splitlines():
+            if re.search(r"\bv_pk_\w+_f32\b", line):
+                total += 1
+                opsel += "op_sel:" in line
+    return total, opsel
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

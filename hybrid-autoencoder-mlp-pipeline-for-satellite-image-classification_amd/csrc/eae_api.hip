@@ -77,6 +77,8 @@ struct eae_ctx {
   static constexpr int NEV = 16;
   hipEvent_t ev_fork[NEV] = {};
   hipEvent_t ev_join = nullptr;
+  hipEvent_t ev_head = nullptr;    // classification head finished on the side stream
+  bool head_side = false, head_pending = false;
   int ev_i = 0;
   bool use_side = true;
   // hipGraph replay of the whole train step: ~80 launches + fork/join events per step make the eager path host-bound
@@ -98,7 +100,7 @@ struct eae_ctx {
   static constexpr int PROF_RING = 64;
   bool prof_on = false;
   int prof_n = 0;
-  hipEvent_t prof_ev[2 * PROF_RING] = {};
+  hipEvent_t prof_ev[3 * PROF_RING] = {};     // per sample: before, after, after an EMPTY bracket (calibration)
   long long act_elems(int lvl) const {   // per-image elements of the map after `lvl` stride-2 stages (1..4)
     return (long long)(H >> lvl) * (W >> lvl) * ENC_C[lvl];
   }
@@ -204,6 +206,8 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
     e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     for (int i = 0; i < eae_ctx::NEV && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_head, hipEventDisableTiming);
+    c->head_side = getenv("EAE_HEAD_MAIN") == nullptr;     // the head only needs z: it runs beside the decoder
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_main, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
@@ -225,30 +229,34 @@ extern "C" int eae_debug_copy(eae_ctx* c, int which, float* dst, long long n) {
 extern "C" int eae_profile_enable(eae_ctx* c, int on) {
   if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL");
   if (on && !c->prof_ev[0])
-    for (int i = 0; i < 2 * eae_ctx::PROF_RING; ++i) EAE_HIP(hipEventCreate(&c->prof_ev[i]));
+    for (int i = 0; i < 3 * eae_ctx::PROF_RING; ++i) EAE_HIP(hipEventCreate(&c->prof_ev[i]));
   c->prof_on = on != 0;
   c->prof_n = 0;
   return 0;
 }
 
-extern "C" int eae_profile_read(eae_ctx* c, double* total_ms, long long* count) {
+extern "C" int eae_profile_read2(eae_ctx* c, double* total_ms, double* empty_ms, long long* count) {
   if (!c || !total_ms || !count) return eae_set_error(EAE_ERR_ARG, "profile_read: NULL argument");
-  double tot = 0.0;
+  double tot = 0.0, emp = 0.0;
   for (int i = 0; i < c->prof_n; ++i) {
     float ms = 0.f;
-    EAE_HIP(hipEventSynchronize(c->prof_ev[2 * i + 1]));
-    EAE_HIP(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+    EAE_HIP(hipEventSynchronize(c->prof_ev[3 * i + 2]));
+    EAE_HIP(hipEventElapsedTime(&ms, c->prof_ev[3 * i], c->prof_ev[3 * i + 1]));
     tot += ms;
+    EAE_HIP(hipEventElapsedTime(&ms, c->prof_ev[3 * i + 1], c->prof_ev[3 * i + 2]));
+    emp += ms;
   }
   *total_ms = tot; *count = c->prof_n;
+  if (empty_ms) *empty_ms = emp;
   c->prof_n = 0;
   return 0;
 }
+extern "C" int eae_profile_read(eae_ctx* c, double* total_ms, long long* count) { return eae_profile_read2(c, total_ms, nullptr, count); }
 
 extern "C" int eae_destroy(eae_ctx* c) {
   if (!c) return 0;
   hipDeviceSynchronize();
-  if (c->prof_ev[0]) for (int i = 0; i < 2 * eae_ctx::PROF_RING; ++i) hipEventDestroy(c->prof_ev[i]);
+  if (c->prof_ev[0]) for (int i = 0; i < 3 * eae_ctx::PROF_RING; ++i) hipEventDestroy(c->prof_ev[i]);
   for (int i = 0; i < c->ngraphs; ++i) {
     if (c->graphs[i].exec) hipGraphExecDestroy(c->graphs[i].exec);
     if (c->graphs[i].graph) hipGraphDestroy(c->graphs[i].graph);
@@ -256,6 +264,7 @@ extern "C" int eae_destroy(eae_ctx* c) {
   if (c->side) {
     for (int i = 0; i < eae_ctx::NEV; ++i) hipEventDestroy(c->ev_fork[i]);
     hipEventDestroy(c->ev_join);
+    if (c->ev_head) hipEventDestroy(c->ev_head);
     hipStreamDestroy(c->side);
     if (c->own_main) { hipStreamDestroy(c->own_main); hipEventDestroy(c->ev_in); hipEventDestroy(c->ev_out); }
   }
@@ -344,9 +353,13 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
     a.stat_part = train ? c->stat : nullptr;
     a.B = B; a.Hin = H >> i; a.Win = W >> i;
     const bool prof = c->prof_on && i == 1 && c->prof_n < eae_ctx::PROF_RING;
-    if (prof) EAE_HIP(hipEventRecord(c->prof_ev[2 * c->prof_n], st));
+    if (prof) EAE_HIP(hipEventRecord(c->prof_ev[3 * c->prof_n], st));
     RC(eae_launch_conv_s2(a, ENC_C[i], ENC_C[i + 1], SRC_BNRELU, EPI_FWD, st));
-    if (prof) { EAE_HIP(hipEventRecord(c->prof_ev[2 * c->prof_n + 1], st)); c->prof_n++; }
+    if (prof) {     // second pair with nothing in between: what two event records cost by themselves on this stream
+      EAE_HIP(hipEventRecord(c->prof_ev[3 * c->prof_n + 1], st));
+      EAE_HIP(hipEventRecord(c->prof_ev[3 * c->prof_n + 2], st));
+      c->prof_n++;
+    }
     RC(bn_fwd_finalize(c, st, i, eae_conv_s2_ntiles(0, B, a.Hin, a.Win), (long long)B * (a.Hin / 2) * (a.Win / 2), train));
   }
   FcNtArgs f = FcNtArgs();
@@ -426,10 +439,19 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
   const float gscale = (float)(2.0 * io->alpha / numel);
   const bool want_loss = io->loss_accum || io->loss_last;
   const bool head = io->head != 0;
-  // The head only needs z and could run beside the decoder on the side stream, but head_kernel co-resident with the
-  // igemm kernels produced run-to-run differences in single rows (root cause not found this round: inputs and the final z
-  // are identical, no buffer is shared); it therefore stays on the main stream.  DESIGN.md, open issues.
-  if (head) RC(run_head(c, st, B, io->labels, io->logits, want_grad, nullptr));
+  // The head only needs z: in a gradient step it runs on the side stream beside the decoder; the backward waits for it
+  // (ev_head) right before dz_cls is added to dz.  (head_kernel is built without packed-FP32 instructions, see EAE_NO_PK.)
+  if (head) {
+    if (want_grad && c->head_side && c->use_side) {
+      hipStream_t hs;
+      RC(fork_side(c, st, &hs));
+      RC(run_head(c, hs, B, io->labels, io->logits, want_grad, nullptr));
+      EAE_HIP(hipEventRecord(c->ev_head, hs));
+      c->head_pending = true;
+    } else {
+      RC(run_head(c, st, B, io->labels, io->logits, want_grad, nullptr));
+    }
+  }
   RC(run_decoder(c, st, c->z, B, train, (want_loss || want_grad) ? io->x : nullptr, gscale, io->x_hat, want_grad, want_loss));
   if (io->z) EAE_HIP(hipMemcpyAsync(io->z, c->z, (size_t)B * c->L * 4, hipMemcpyDeviceToDevice, st));
   if (want_loss || want_grad) {
@@ -509,6 +531,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     f.M = B; f.N = c->L; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
     const int ksplit = (int)(c->K / 128);
     RC(eae_launch_fc_nt(st, f, SRC_RAW, FCE_PARTIAL, ksplit));
+    if (c->head_pending) { EAE_HIP(hipStreamWaitEvent(st, c->ev_head, 0)); c->head_pending = false; }
     RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, nullptr, head ? c->dzc : nullptr, dz_ext, c->dz));
   }
   }   // part != 2

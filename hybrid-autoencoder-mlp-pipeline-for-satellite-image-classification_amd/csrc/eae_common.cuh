@@ -138,4 +138,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* row_ptr_lo, const bf16_t
   return u.v;
 }
 
+// Kernels WITHOUT matrix instructions that may be co-resident with the MFMA kernels (second stream, other processes' work)
+// are built without packed-FP32 VALU instructions: on gfx950 / ROCm 7.2 code with v_pk_fma_f32 / v_pk_mul_f32 op_sel chains
+// returned wrong low-half results in lanes 48-63 when an MFMA kernel shared the SIMD (tools/race_*.py:
+// reproduced with a register-only victim; the same source built with this attribute is immune).
+#define EAE_NO_PK __attribute__((target("no-packed-fp32-ops")))
+
 #define EAE_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return eae_set_error(-3, hipGetErrorString(e__)); } while (0)

@@ -106,8 +106,11 @@ __global__ __launch_bounds__(256) void edge_conv_kernel(EdgeArgs a) {
   const int txb = t % tiles_x; t /= tiles_x;
   const int tyb = t % tiles_y; t /= tiles_y;
   const int n = t;
-  stage_patch3<SRC3>(a.src3, p3, n, a.H, a.W, 2 * tyb * E_TH - 1, 2 * txb * E_TW - 1);
-  build_im2col27(p3, at);
+#ifndef EAE_DIAG
+#define EAE_DIAG 0
+#endif
+  if (!(EAE_DIAG & 1)) stage_patch3<SRC3>(a.src3, p3, n, a.H, a.W, 2 * tyb * E_TH - 1, 2 * txb * E_TW - 1);
+  if (!(EAE_DIAG & 2)) build_im2col27(p3, at);
   __syncthreads();
   const int kgl = lane >> 4;
   f32x4 acc[2][2];
@@ -121,8 +124,12 @@ __global__ __launch_bounds__(256) void edge_conv_kernel(EdgeArgs a) {
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma16(af[mi], bfr[ni], (f32x4){0.f, 0.f, 0.f, 0.f});
+    for (int ni = 0; ni < 2; ++ni) {
+      if (EAE_DIAG & 4) acc[mi][ni] = (f32x4){af[mi][0], bfr[ni][1], 0.f, 1.f};
+      else acc[mi][ni] = mfma16(af[mi], bfr[ni], (f32x4){0.f, 0.f, 0.f, 0.f});
+    }
   __syncthreads();
+  if (EAE_DIAG & 8) { if (acc[0][0][0] == 1234.5f) a.c.out[0] = 1; return; }
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     int col = ni * 16 + (lane & 15);

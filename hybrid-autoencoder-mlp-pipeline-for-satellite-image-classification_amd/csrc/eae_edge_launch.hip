@@ -59,7 +59,7 @@ int eae_launch_deconv4_loss(hipStream_t st, int smode, const Deconv4Args& a) {
 
 // g4[n,oy,ox,c] = bf16(dx_hat * x_hat * (1 - x_hat))   (backward of nn.Sigmoid, R.md:383, for an externally supplied dL/dx_hat)
 // fp32 NCHW in, bf16 NHWC4 out; part[block][4] = {0, sum g(c=0), sum g(c=1), sum g(c=2)} (bias gradient of deconv4)
-__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ xh, const float* __restrict__ dxh, bf16_t* __restrict__ g4,
+__global__ EAE_NO_PK __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ xh, const float* __restrict__ dxh, bf16_t* __restrict__ g4,
                                                            float* __restrict__ part, long npix_total, long plane) {
   __shared__ float red[4][4];
   const long p = (long)blockIdx.x * 256 + threadIdx.x;      // pixel index n*H*W + oy*W + ox

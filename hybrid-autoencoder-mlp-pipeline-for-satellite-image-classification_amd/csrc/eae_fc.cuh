@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs a) {
 
 // z (or dz) = bias + sum over K-slices of the split-K partials (+ optional addends), fp32; 16 float4 lanes x 16 slice
 // lanes per block, fixed summation order
-static __global__ __launch_bounds__(256) void fc_splitk_reduce_kernel(const float* __restrict__ part, int nsl, int M, int N,
+static __global__ EAE_NO_PK __launch_bounds__(256) void fc_splitk_reduce_kernel(const float* __restrict__ part, int nsl, int M, int N,
                                                                 const float* __restrict__ bias, const float* __restrict__ addend,
                                                                 const float* __restrict__ addend2, float* __restrict__ out) {
   __shared__ float4 red[16][16];

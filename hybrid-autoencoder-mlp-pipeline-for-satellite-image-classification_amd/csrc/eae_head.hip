@@ -8,7 +8,7 @@
 
 constexpr int HR = 8;   // batch rows per block
 
-__global__ __launch_bounds__(256) void head_kernel(HeadArgs a) {
+__global__ EAE_NO_PK __launch_bounds__(256) void head_kernel(HeadArgs a) {
   extern __shared__ float sm[];
   const int L = a.L, C = a.C, LS = L + 1;
   float* w1 = sm;                    // [128][L+1]
@@ -148,7 +148,7 @@ int eae_launch_head(hipStream_t st, const HeadArgs& a) {
 //   accum[0] += loss*B, accum[1] += mse*B, accum[2] += ce*B, accum[3] += B, accum[4] += correct
 //   last[0..2] = loss, mse, ce of this step
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* mse_part, int n_mse, const float* ce_part, int n_ce, float alpha,
+__global__ EAE_NO_PK __launch_bounds__(256) void loss_finalize_kernel(const float* mse_part, int n_mse, const float* ce_part, int n_ce, float alpha,
                                                              float inv_numel, float B, float* db4, float* accum, float* last) {
   __shared__ double red[256][6];
   const int tid = threadIdx.x;
@@ -183,7 +183,7 @@ int eae_launch_loss_finalize(hipStream_t st, const float* mse_part, int n_mse, c
 }
 
 // op-level helper: out2[0] = mean CE over the batch, out2[1] = number of correct argmax (fixed-order sum of the block partials)
-__global__ void ce_mean_kernel(const float* ce_part, int n, float B, float* out2) {
+__global__ EAE_NO_PK void ce_mean_kernel(const float* ce_part, int n, float B, float* out2) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double s = 0.0, c = 0.0;
   for (int i = 0; i < n; ++i) { s += ce_part[2 * i]; c += ce_part[2 * i + 1]; }

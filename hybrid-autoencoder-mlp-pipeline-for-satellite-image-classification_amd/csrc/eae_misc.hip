@@ -30,7 +30,7 @@ __device__ __forceinline__ void reduce_partials_ch(const float* __restrict__ par
 // running_mean/var updated with momentum (unbiased variance), num_batches_tracked += 1   
 // grid = C blocks (one channel each) of 256 threads.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int ntiles, int C, float count,
+__global__ EAE_NO_PK __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int ntiles, int C, float count,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* running_mean, float* running_var, long long* nbt,
                                                            float momentum, float eps, float* __restrict__ coef) {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 }
 
 // eval mode: coefficients from the running statistics
-__global__ void bn_eval_coef_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+__global__ EAE_NO_PK void bn_eval_coef_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                     float* coef) {
   int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= C) return;
@@ -74,7 +74,7 @@ __global__ void bn_eval_coef_kernel(int C, const float* gamma, const float* beta
 // BatchNorm backward finalize.  part = [2][C][ntiles] (sum g, sum g*xhat), g = ReLU-masked upstream gradient.
 //   dbeta = sum g ; dgamma = sum g*xhat ;  dy = A*g + B*y + Cc  with
 //   A = gamma*invstd, B = -A*invstd*dgamma/N, Cc = -A*dbeta/N + A*invstd*mean*dgamma/N   (native_batch_norm_backward)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int ntiles, int C, float count,
+__global__ EAE_NO_PK __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int ntiles, int C, float count,
                                                                const float* __restrict__ gamma, const float* __restrict__ coef_fwd,
                                                                float* dgamma, float* dbeta, float* __restrict__ coef_bwd) {
   __shared__ double red[512];
@@ -170,7 +170,7 @@ __device__ __forceinline__ float pack_fetch(const PackDesc& d, const float* __re
   }
 }
 
-__global__ __launch_bounds__(256) void pack_all_kernel(const PackDesc* __restrict__ descs, const float* __restrict__ params,
+__global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc* __restrict__ descs, const float* __restrict__ params,
                                                         uint8_t* __restrict__ pack_base) {
   const PackDesc d = descs[blockIdx.y];
   const float* src = params + d.src_off;
@@ -191,7 +191,7 @@ int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, co
 // Fused multi-tensor Adam over the flat fp32 arenas (torch.optim.Adam defaults, R.md:624; L2 decay for the MLP, R.md:2625)
 //   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ EAE_NO_PK __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n4, float b1, float b2, float step_size,
                                                     float bc2_sqrt, float eps, float wd, float gscale) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 // Same update with the per-step scalars (lr/bias_correction1, sqrt(bias_correction2), weight decay) read from device memory,
 // so that a captured hipGraph of the whole train step can be replayed while the step count advances.
-__global__ __launch_bounds__(256) void adam_dyn_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ EAE_NO_PK __launch_bounds__(256) void adam_dyn_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n4, float b1, float b2, float eps,
                                                         const float* __restrict__ dyn) {
   const float step_size = dyn[0], bc2_sqrt = dyn[1], wd = dyn[2];
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void adam_dyn_kernel(float* __restrict__ p, co
     reinterpret_cast<float4*>(v)[i] = vv;
   }
 }
-__global__ void set_dyn_kernel(float* dyn, float a, float b, float c) { dyn[0] = a; dyn[1] = b; dyn[2] = c; }
+__global__ EAE_NO_PK void set_dyn_kernel(float* dyn, float a, float b, float c) { dyn[0] = a; dyn[1] = b; dyn[2] = c; }
 
 int eae_launch_adam_dyn(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double b1, double b2, double eps,
                         const float* dyn) {
@@ -296,7 +296,7 @@ __device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, u
   o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
-__global__ __launch_bounds__(256) void augment_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+__global__ EAE_NO_PK __launch_bounds__(256) void augment_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int B, int H, int W,
                                                        int train, float std, unsigned long long seed, unsigned long long step,
                                                        const int* __restrict__ params, const float* __restrict__ noise) {
   const long plane = (long)H * W;

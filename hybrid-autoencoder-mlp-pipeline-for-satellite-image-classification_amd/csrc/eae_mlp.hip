@@ -85,7 +85,7 @@ __device__ void col_sums2(const float* g, const float* h, const float* s_mean, c
   __syncthreads();
 }
 
-__global__ __launch_bounds__(T) void mlp_kernel(MlpArgs a) {
+__global__ EAE_NO_PK __launch_bounds__(T) void mlp_kernel(MlpArgs a) {
   __shared__ float red[2 * T];
   __shared__ float mean1[H1], var1[H1], inv1[H1], mean2[H2], var2[H2], inv2[H2], c1[H1], c2[H1];
   const int tid = threadIdx.x;

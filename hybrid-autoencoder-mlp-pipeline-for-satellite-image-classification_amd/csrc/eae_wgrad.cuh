@@ -168,7 +168,7 @@ __device__ __forceinline__ void reduce_slices_body(const float* __restrict__ par
 }
 
 // out[i] = sum_s part[s][i]
-static __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ part, int nslices, long n4,
+static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ part, int nslices, long n4,
                                                                    float* __restrict__ out, float scale) {
   reduce_slices_body(part, nslices, n4, [=](long i, float4 r) {
     r.x *= scale; r.y *= scale; r.z *= scale; r.w *= scale;
@@ -177,7 +177,7 @@ static __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* 
 }
 
 // out[cs][cb][tap] = sum_s part[s][tap][cs][cb]; thread = 4 consecutive cb of one (tap, cs)
-static __global__ __launch_bounds__(256) void reduce_slices_perm_kernel(const float* __restrict__ part, int nslices, int CS, int CB,
+static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_perm_kernel(const float* __restrict__ part, int nslices, int CS, int CB,
                                                                         float* __restrict__ out) {
   reduce_slices_body(part, nslices, (long)9 * CS * CB / 4, [=](long i, float4 r) {
     long e = i * 4;

@@ -9,6 +9,8 @@ The collective goes through ``torch.distributed`` so that the same code runs on 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -62,6 +64,12 @@ class DataParallelTrainer:
             eng.grad_step(x, labels, alpha, head=head)
             self.allreduce_gradients()
             eng.adam_step(lr)
+            return
+        if os.environ.get("EAE_DP_OVERLAP", "1") == "0":     # collectives strictly after the backward
+            eng.grad_step(x, labels, alpha, head=head)
+            for lo, hi in ((eng.poff[18], eng.poff[38]), (0, eng.poff[18])):
+                dist.all_reduce(eng.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+            eng.adam_step(lr, grad_scale=1.0 / self.world)
             return
         cut = eng.poff[18]
         total = eng.poff[38]

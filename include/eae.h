@@ -106,6 +106,9 @@ int eae_profile_enable(eae_ctx* ctx, int on);
 /* diagnostic: copy an internal fp32 buffer (0 z, 1 dz, 2 dz_head, 3 head partials, 4 CE partials) to dst (device) */
 int eae_debug_copy(eae_ctx* ctx, int which, float* dst, long long n);
 int eae_profile_read(eae_ctx* ctx, double* total_ms, long long* count);
+/* same, plus the summed duration of an EMPTY event bracket recorded right after each timed one (the cost of the two event
+ * records themselves; subtracting it gives the kernel's own duration, which is what rocprofv3 reports) */
+int eae_profile_read2(eae_ctx* ctx, double* total_ms, double* empty_ms, long long* count);
 
 /* ------------------------------------------------------------------ per-op entry points ---------------------- */
 /* Building blocks of the fused step, exported for kernel-level parity tests.  Activations are NHWC bf16. */
