@@ -77,11 +77,30 @@ def kernel_roofline(eng, step_fn, batch):
     r = PH.dominant_kernel_roofline(eng, step_fn, batch, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFLOPS)
     # HBM traffic of that kernel from the PMC counters: collected with rocprofv3 in separate --pmc passes of this same
     # command (they cannot be read from inside the process) and committed under profiles/
+    kname = "void igemm_s2_kernel<0, 32, 64, 64, 16, 8, 1, 1, 0>(ConvArgs)"
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_b512.json")
     if batch == BATCH and os.path.exists(pmc):
-        k = json.load(open(pmc))["kernels"].get("void igemm_s2_kernel<0, 32, 64, 64, 16, 8, 1, 1, 0>(ConvArgs)")
+        k = json.load(open(pmc))["kernels"].get(kname)
         if k:
             r["traffic"] = k["traffic_bytes"]
+    # The committed rocprofv3 --kernel-trace --stats summary of this same command (profiles/) is the cross-check: its average
+    # for this kernel includes the command processor's dispatch/completion overhead (an empty kernel reads >= 2 us there), so
+    # it sits above the calibrated event time.  `achieved` is priced on the SLOWER of the two, so the claim never exceeds what
+    # the committed profile supports.
+    import csv
+    import glob
+    stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_b512_kernel_stats_v*.csv")),
+                   key=lambda p: int(p.rsplit("_v", 1)[1].split(".")[0]))
+    if batch == BATCH and stats:
+        for row in csv.DictReader(open(stats[-1])):
+            if row["Name"] == kname:
+                r["rocprof_avg_us"] = round(float(row["AverageNs"]) / 1e3, 2)
+                r["rocprof_summary"] = os.path.relpath(stats[-1], ROOT)
+    us = max(r["avg_launch_us"], r.get("rocprof_avg_us", 0.0))
+    r["priced_us"] = us
+    r["achieved"] = round(r["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9, 1)
+    r["frac"] = round(r["achieved"] / HBM_PEAK_GBS, 4)
+    r["tflops"] = round(batch * PH.CONV2_FLOP_PER_IMG / (us * 1e-6) / 1e12, 1)
     return r
 
 
