@@ -130,7 +130,7 @@ __global__ EAE_NO_PK __launch_bounds__(256) void head_kernel(HeadArgs a) {
 }
 
 int eae_launch_head(hipStream_t st, const HeadArgs& a) {
-  if (a.L > 128 || a.C > 16 || a.L % 4) return eae_set_error(-2, "head: latent_dim must be <= 128 (multiple of 4), classes <= 16");
+  if (a.L > 256 || a.C > 16 || a.L % 4) return eae_set_error(-2, "head: latent_dim must be <= 256 (multiple of 4), classes <= 16");
   size_t smem = sizeof(float) * ((size_t)128 * (a.L + 1) + HR * a.L + a.C * 128 + 2 * HR * 129 + HR * 16 + 128 + 16 + 2 * HR);
   static size_t attr = 0;
   if (smem > attr) {
