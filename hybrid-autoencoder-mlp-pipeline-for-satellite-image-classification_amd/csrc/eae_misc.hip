@@ -7,7 +7,13 @@
 
 
 // Sum the partials of ONE channel: part = [2][C][ntiles] (channel-major, so the reads are contiguous); 256 threads stride
-// over the tiles, fp64 accumulation, fixed-order LDS tree -> bitwise reproducible.
+// over the tiles with fp64 accumulation, then a fixed-order reduction: xor-butterfly inside each wave (every lane ends with
+// the wave's sum), the four wave sums added in wave order -> bitwise reproducible, one barrier instead of a 9-step LDS tree.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 __device__ __forceinline__ void reduce_partials_ch(const float* __restrict__ part, int ntiles, int C, int ch, double* red,
                                                    double& a, double& b) {
   const int tid = threadIdx.x;
@@ -15,13 +21,11 @@ __device__ __forceinline__ void reduce_partials_ch(const float* __restrict__ par
   const float* p2 = part + ((size_t)C + ch) * ntiles;
   double s1 = 0.0, s2 = 0.0;
   for (int t = tid; t < ntiles; t += 256) { s1 += (double)p1[t]; s2 += (double)p2[t]; }
-  red[tid] = s1; red[256 + tid] = s2;
+  s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);
+  if ((tid & 63) == 0) { red[tid >> 6] = s1; red[4 + (tid >> 6)] = s2; }
   __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if (tid < o) { red[tid] += red[tid + o]; red[256 + tid] += red[256 + tid + o]; }
-    __syncthreads();
-  }
-  a = red[0]; b = red[256];
+  a = ((red[0] + red[1]) + red[2]) + red[3];
+  b = ((red[4] + red[5]) + red[6]) + red[7];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
