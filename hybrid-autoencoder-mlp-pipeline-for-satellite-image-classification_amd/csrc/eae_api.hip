@@ -72,6 +72,10 @@ struct eae_ctx {
   // second stream: weight-gradient kernels, the classifier head and the slice reductions do not sit on the
   // forward / backward-data dependency chain, so they run concurrently with it (fork/join through events)
   hipStream_t side = nullptr;
+  hipStream_t side2 = nullptr;     // second side stream: weight-gradient groups alternate, so a layer's slice reduction overlaps the next layer's wgrad
+  hipEvent_t ev_join2 = nullptr, ev_s2 = nullptr;
+  float* wscratch2 = nullptr;      // split-K partials of the groups on side2
+  int side_rr = 0;
   hipStream_t own_main = nullptr;  // capture is not permitted on the legacy default stream: graphs run here, bracketed by events
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   static constexpr int NEV = 16;
@@ -152,7 +156,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   }
   size_t o_stat = carve(stat_floats * 4);
   c->wscratch_floats = 6LL * 1024 * 1024;    // 24 MB of fp32 split-K partials
-  size_t o_wscr = carve(c->wscratch_floats * 4);
+  size_t o_wscr = carve(c->wscratch_floats * 4), o_wscr2 = carve(c->wscratch_floats * 4);
   const int ksplit = (int)(c->K / 128);
   size_t o_fcp = carve((size_t)ksplit * Bm * c->L * 4);
   size_t o_mse = carve(std::max((size_t)eae_edge_tiles((int)Bm, c->H, c->W), (size_t)((Bm * c->H * c->W + 255) / 256)) * 4 * 4);
@@ -191,7 +195,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->d0 = (bf16_t*)(b + o_d0); c->gd0 = (bf16_t*)(b + o_gd0); c->g4 = (bf16_t*)(b + o_g4);
   c->z = (float*)(b + o_z); c->dz = (float*)(b + o_dz); c->dzc = (float*)(b + o_dzc);
   for (int l = 0; l < 7; ++l) { c->coef_f[l] = (float*)(b + o_cf[l]); c->coef_b[l] = (float*)(b + o_cb[l]); }
-  c->stat = (float*)(b + o_stat); c->wscratch = (float*)(b + o_wscr); c->fcpart = (float*)(b + o_fcp);
+  c->stat = (float*)(b + o_stat); c->wscratch = (float*)(b + o_wscr); c->wscratch2 = (float*)(b + o_wscr2); c->fcpart = (float*)(b + o_fcp);
   c->msepart = (float*)(b + o_mse); c->cepart = (float*)(b + o_ce); c->headpart = (float*)(b + o_head); c->lossbuf = (float*)(b + o_loss);
   c->pack = b + o_pack; c->descs_dev = (PackDesc*)(b + o_desc);
   c->dyn = (float*)(b + o_dyn);
@@ -204,6 +208,11 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->use_side = getenv("EAE_NO_SIDE_STREAM") == nullptr;
   if (c->use_side) {
     e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess && getenv("EAE_ONE_SIDE_STREAM") == nullptr) {
+      e = hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_s2, hipEventDisableTiming);
+    }
     for (int i = 0; i < eae_ctx::NEV && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_head, hipEventDisableTiming);
@@ -266,6 +275,7 @@ extern "C" int eae_destroy(eae_ctx* c) {
     hipEventDestroy(c->ev_join);
     if (c->ev_head) hipEventDestroy(c->ev_head);
     hipStreamDestroy(c->side);
+    if (c->side2) { hipStreamDestroy(c->side2); hipEventDestroy(c->ev_join2); hipEventDestroy(c->ev_s2); }
     if (c->own_main) { hipStreamDestroy(c->own_main); hipEventDestroy(c->ev_in); hipEventDestroy(c->ev_out); }
   }
   if (c->ws) hipFree(c->ws);
@@ -300,11 +310,38 @@ int fork_side(eae_ctx* c, hipStream_t st, hipStream_t* out) {
   *out = c->side;
   return 0;
 }
-// join: work enqueued on `st` from now on starts after everything enqueued so far on the side stream
+// fork for a weight-gradient group (wgrad + its slice reduction): the groups alternate between the two side streams, each
+// with its own split-K scratch, so the reduction of one layer runs beside the wgrad kernel of the next
+int fork_wgrad(eae_ctx* c, hipStream_t st, hipStream_t* out, float** scratch) {
+  *scratch = c->wscratch;
+  if (!c->use_side || !c->side2) return fork_side(c, st, out);
+  const bool second = (c->side_rr++ & 1) != 0;
+  if (!second) return fork_side(c, st, out);
+  hipEvent_t ev = c->ev_fork[c->ev_i];
+  c->ev_i = (c->ev_i + 1) % eae_ctx::NEV;
+  EAE_HIP(hipEventRecord(ev, st));
+  EAE_HIP(hipStreamWaitEvent(c->side2, ev, 0));
+  *out = c->side2;
+  *scratch = c->wscratch2;
+  return 0;
+}
+// everything enqueued so far on the second side stream completes before later work on the first one (the DP path hands
+// `side` to the all-reduce)
+int fold_side2(eae_ctx* c) {
+  if (!c->use_side || !c->side2) return 0;
+  EAE_HIP(hipEventRecord(c->ev_s2, c->side2));
+  EAE_HIP(hipStreamWaitEvent(c->side, c->ev_s2, 0));
+  return 0;
+}
+// join: work enqueued on `st` from now on starts after everything enqueued so far on the side streams
 int join_side(eae_ctx* c, hipStream_t st) {
   if (!c->use_side) return 0;
   EAE_HIP(hipEventRecord(c->ev_join, c->side));
   EAE_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
+  if (c->side2) {
+    EAE_HIP(hipEventRecord(c->ev_join2, c->side2));
+    EAE_HIP(hipStreamWaitEvent(st, c->ev_join2, 0));
+  }
   return 0;
 }
 
@@ -470,7 +507,9 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
 int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float* dz_ext = nullptr, int part = 0) {
   const int B = io->B, H = c->H, W = c->W;
   const bool head = io->head != 0;
-  hipStream_t ss;       // side stream: everything that only feeds the optimizer (weight gradients and their reductions)
+  hipStream_t ss;       // side streams: everything that only feeds the optimizer (weight gradients and their reductions)
+  float* scr = c->wscratch;
+  c->side_rr = 0;
   RC(fork_side(c, st, &ss));
   if (part != 2) {
   // ---- classifier weight gradients (partials written by the head kernel)
@@ -483,7 +522,8 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     EAE_HIP(hipMemsetAsync(c->G + c->poff[34], 0, (size_t)(c->poff[38] - c->poff[34]) * 4, ss));
   }
   // ---- deconv4: weight gradient, then backward-data into u[2]'s BN+ReLU
-  RC(eae_launch_edge_wgrad(ss, SRC3_NHWC4_BF16, c->g4, B, H, W, src_bnrelu(c->u[2], c->coef_f[6]), SRC_BNRELU, c->wscratch,
+  RC(fork_wgrad(c, st, &ss, &scr));
+  RC(eae_launch_edge_wgrad(ss, SRC3_NHWC4_BF16, c->g4, B, H, W, src_bnrelu(c->u[2], c->coef_f[6]), SRC_BNRELU, scr,
                            c->wscratch_floats, c->G + c->poff[32]));
   {
     EdgeArgs a;
@@ -503,8 +543,8 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     w.small = (i == 0) ? src_raw(c->d0) : src_bnrelu(c->u[i - 1], c->coef_f[3 + i]);
     w.big = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
     w.B = B; w.Hs = Hs; w.Ws = Ws;
-    RC(fork_side(c, st, &ss));       // needs coef_b[4+i] (BN-backward finalize of this layer's output)
-    RC(eae_launch_wgrad_s2(ss, w, cs, cb, i == 0 ? SRC_RAW : SRC_BNRELU, SRC_BNBWD, c->wscratch, c->wscratch_floats,
+    RC(fork_wgrad(c, st, &ss, &scr));       // needs coef_b[4+i] (BN-backward finalize of this layer's output)
+    RC(eae_launch_wgrad_s2(ss, w, cs, cb, i == 0 ? SRC_RAW : SRC_BNRELU, SRC_BNBWD, scr, c->wscratch_floats,
                            c->G + c->poff[20 + 4 * i]));
     ConvArgs a = ConvArgs();
     a.src = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
@@ -524,7 +564,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     FcTnArgs t = FcTnArgs();
     t.p = src_raw(c->gd0); t.q = src_f32(c->z); t.Bt = B; t.I = (int)c->K; t.J = c->L;
     t.out = c->G + c->poff[18]; t.colsum = c->G + c->poff[19]; t.out_mode = 0; t.Pn = (int)c->Pn;
-    RC(fork_side(c, st, &ss));       // needs gd0
+    RC(fork_wgrad(c, st, &ss, &scr));       // needs gd0
     RC(eae_launch_fc_tn(ss, t, SRC_RAW, SRC_F32));
     FcNtArgs f = FcNtArgs();
     f.a = src_raw(c->gd0); f.w = (const bf16_t*)(c->pack + c->pk_wd2);
@@ -535,13 +575,13 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, nullptr, head ? c->dzc : nullptr, dz_ext, c->dz));
   }
   }   // part != 2
-  if (part == 1) return 0;     // the caller may now all-reduce gradient tensors 18..37 behind the side stream
+  if (part == 1) return fold_side2(c);     // the caller may now all-reduce gradient tensors 18..37 behind the side stream
   // ---- enc.fc: weight/bias gradient and backward-data into y[3]'s BN+ReLU
   {
     FcTnArgs t = FcTnArgs();
     t.p = src_f32(c->dz); t.q = src_bnrelu(c->y[3], c->coef_f[3]); t.Bt = B; t.I = c->L; t.J = (int)c->K;
     t.out = c->G + c->poff[16]; t.colsum = c->G + c->poff[17]; t.out_mode = 1; t.Pn = (int)c->Pn;
-    RC(fork_side(c, st, &ss));       // needs dz
+    RC(fork_wgrad(c, st, &ss, &scr));       // needs dz
     RC(eae_launch_fc_tn(ss, t, SRC_F32, SRC_BNRELU));
     FcNtArgs f = FcNtArgs();
     f.a = src_f32(c->dz); f.w = (const bf16_t*)(c->pack + c->pk_we2);
@@ -559,8 +599,8 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     w.small = src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
     w.big = src_bnrelu(c->y[i - 1], c->coef_f[i - 1]);
     w.B = B; w.Hs = Hs; w.Ws = Ws;
-    RC(fork_side(c, st, &ss));       // needs coef_b[i]
-    RC(eae_launch_wgrad_s2(ss, w, cs, cb, SRC_BNBWD, SRC_BNRELU, c->wscratch, c->wscratch_floats, c->G + c->poff[4 * i]));
+    RC(fork_wgrad(c, st, &ss, &scr));       // needs coef_b[i]
+    RC(eae_launch_wgrad_s2(ss, w, cs, cb, SRC_BNBWD, SRC_BNRELU, scr, c->wscratch_floats, c->G + c->poff[4 * i]));
     ConvArgs a = ConvArgs();
     a.src = src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
     a.wpack = (const bf16_t*)(c->pack + c->pk_p2[i - 1]);
@@ -570,8 +610,8 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     RC(bn_bwd_fin(c, st, i - 1, eae_conv_s2_ntiles(1, B, Hs, Ws), (long long)B * (Hs * 2) * (Ws * 2)));
   }
   // ---- conv1 weight gradient
-  RC(fork_side(c, st, &ss));         // needs coef_b[0]
-  RC(eae_launch_edge_wgrad(ss, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, c->wscratch,
+  RC(fork_wgrad(c, st, &ss, &scr));         // needs coef_b[0]
+  RC(eae_launch_edge_wgrad(ss, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, scr,
                            c->wscratch_floats, c->G + c->poff[0]));
   RC(join_side(c, st));
   // Biases in front of a BatchNorm have an identically zero gradient (the reference computes ~1e-9 rounding noise);
