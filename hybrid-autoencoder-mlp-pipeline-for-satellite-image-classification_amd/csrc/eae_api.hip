@@ -72,9 +72,13 @@ struct eae_ctx {
   // second stream: weight-gradient kernels, the classifier head and the slice reductions do not sit on the
   // forward / backward-data dependency chain, so they run concurrently with it (fork/join through events)
   hipStream_t side = nullptr;
-  hipStream_t side2 = nullptr;     // second side stream: weight-gradient groups alternate, so a layer's slice reduction overlaps the next layer's wgrad
-  hipEvent_t ev_join2 = nullptr, ev_s2 = nullptr;
-  float* wscratch2 = nullptr;      // split-K partials of the groups on side2
+  // extra side streams: weight-gradient groups go round-robin over side + these, each with its own split-K scratch, so a
+  // layer's slice reduction overlaps the next layers' wgrad kernels
+  static constexpr int MAXX = 3;
+  int nx = 0;
+  hipStream_t sidex[MAXX] = {};
+  hipEvent_t ev_joinx[MAXX] = {}, ev_sx[MAXX] = {};
+  float* wscratchx[MAXX] = {};
   int side_rr = 0;
   hipStream_t own_main = nullptr;  // capture is not permitted on the legacy default stream: graphs run here, bracketed by events
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -156,7 +160,14 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   }
   size_t o_stat = carve(stat_floats * 4);
   c->wscratch_floats = 6LL * 1024 * 1024;    // 24 MB of fp32 split-K partials
-  size_t o_wscr = carve(c->wscratch_floats * 4), o_wscr2 = carve(c->wscratch_floats * 4);
+  size_t o_wscr = carve(c->wscratch_floats * 4), o_wscrx[eae_ctx::MAXX];
+  {
+    const char* e = getenv("EAE_SIDE_STREAMS");
+    int ns = e ? atoi(e) : 2;
+    c->nx = ns < 1 ? 0 : (ns - 1 > eae_ctx::MAXX ? eae_ctx::MAXX : ns - 1);
+    if (getenv("EAE_ONE_SIDE_STREAM")) c->nx = 0;
+  }
+  for (int i = 0; i < c->nx; ++i) o_wscrx[i] = carve(c->wscratch_floats * 4);
   const int ksplit = (int)(c->K / 128);
   size_t o_fcp = carve((size_t)ksplit * Bm * c->L * 4);
   size_t o_mse = carve(std::max((size_t)eae_edge_tiles((int)Bm, c->H, c->W), (size_t)((Bm * c->H * c->W + 255) / 256)) * 4 * 4);
@@ -195,7 +206,8 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->d0 = (bf16_t*)(b + o_d0); c->gd0 = (bf16_t*)(b + o_gd0); c->g4 = (bf16_t*)(b + o_g4);
   c->z = (float*)(b + o_z); c->dz = (float*)(b + o_dz); c->dzc = (float*)(b + o_dzc);
   for (int l = 0; l < 7; ++l) { c->coef_f[l] = (float*)(b + o_cf[l]); c->coef_b[l] = (float*)(b + o_cb[l]); }
-  c->stat = (float*)(b + o_stat); c->wscratch = (float*)(b + o_wscr); c->wscratch2 = (float*)(b + o_wscr2); c->fcpart = (float*)(b + o_fcp);
+  c->stat = (float*)(b + o_stat); c->wscratch = (float*)(b + o_wscr);
+  for (int i = 0; i < c->nx; ++i) c->wscratchx[i] = (float*)(b + o_wscrx[i]); c->fcpart = (float*)(b + o_fcp);
   c->msepart = (float*)(b + o_mse); c->cepart = (float*)(b + o_ce); c->headpart = (float*)(b + o_head); c->lossbuf = (float*)(b + o_loss);
   c->pack = b + o_pack; c->descs_dev = (PackDesc*)(b + o_desc);
   c->dyn = (float*)(b + o_dyn);
@@ -208,10 +220,10 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->use_side = getenv("EAE_NO_SIDE_STREAM") == nullptr;
   if (c->use_side) {
     e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
-    if (e == hipSuccess && getenv("EAE_ONE_SIDE_STREAM") == nullptr) {
-      e = hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_s2, hipEventDisableTiming);
+    for (int i = 0; i < c->nx && e == hipSuccess; ++i) {
+      e = hipStreamCreateWithFlags(&c->sidex[i], hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_joinx[i], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sx[i], hipEventDisableTiming);
     }
     for (int i = 0; i < eae_ctx::NEV && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
@@ -275,7 +287,8 @@ extern "C" int eae_destroy(eae_ctx* c) {
     hipEventDestroy(c->ev_join);
     if (c->ev_head) hipEventDestroy(c->ev_head);
     hipStreamDestroy(c->side);
-    if (c->side2) { hipStreamDestroy(c->side2); hipEventDestroy(c->ev_join2); hipEventDestroy(c->ev_s2); }
+    for (int i = 0; i < c->nx; ++i)
+      if (c->sidex[i]) { hipStreamDestroy(c->sidex[i]); hipEventDestroy(c->ev_joinx[i]); hipEventDestroy(c->ev_sx[i]); }
     if (c->own_main) { hipStreamDestroy(c->own_main); hipEventDestroy(c->ev_in); hipEventDestroy(c->ev_out); }
   }
   if (c->ws) hipFree(c->ws);
@@ -310,27 +323,29 @@ int fork_side(eae_ctx* c, hipStream_t st, hipStream_t* out) {
   *out = c->side;
   return 0;
 }
-// fork for a weight-gradient group (wgrad + its slice reduction): the groups alternate between the two side streams, each
-// with its own split-K scratch, so the reduction of one layer runs beside the wgrad kernel of the next
+// fork for a weight-gradient group (wgrad + its slice reduction): the groups go round-robin over the side streams, each
+// with its own split-K scratch, so the reduction of one layer runs beside the wgrad kernels of the next ones
 int fork_wgrad(eae_ctx* c, hipStream_t st, hipStream_t* out, float** scratch) {
   *scratch = c->wscratch;
-  if (!c->use_side || !c->side2) return fork_side(c, st, out);
-  const bool second = (c->side_rr++ & 1) != 0;
-  if (!second) return fork_side(c, st, out);
+  if (!c->use_side || c->nx == 0) return fork_side(c, st, out);
+  const int k = c->side_rr++ % (c->nx + 1);
+  if (k == 0) return fork_side(c, st, out);
   hipEvent_t ev = c->ev_fork[c->ev_i];
   c->ev_i = (c->ev_i + 1) % eae_ctx::NEV;
   EAE_HIP(hipEventRecord(ev, st));
-  EAE_HIP(hipStreamWaitEvent(c->side2, ev, 0));
-  *out = c->side2;
-  *scratch = c->wscratch2;
+  EAE_HIP(hipStreamWaitEvent(c->sidex[k - 1], ev, 0));
+  *out = c->sidex[k - 1];
+  *scratch = c->wscratchx[k - 1];
   return 0;
 }
-// everything enqueued so far on the second side stream completes before later work on the first one (the DP path hands
+// everything enqueued so far on the extra side streams completes before later work on the first one (the DP path hands
 // `side` to the all-reduce)
 int fold_side2(eae_ctx* c) {
-  if (!c->use_side || !c->side2) return 0;
-  EAE_HIP(hipEventRecord(c->ev_s2, c->side2));
-  EAE_HIP(hipStreamWaitEvent(c->side, c->ev_s2, 0));
+  if (!c->use_side) return 0;
+  for (int i = 0; i < c->nx; ++i) {
+    EAE_HIP(hipEventRecord(c->ev_sx[i], c->sidex[i]));
+    EAE_HIP(hipStreamWaitEvent(c->side, c->ev_sx[i], 0));
+  }
   return 0;
 }
 // join: work enqueued on `st` from now on starts after everything enqueued so far on the side streams
@@ -338,9 +353,9 @@ int join_side(eae_ctx* c, hipStream_t st) {
   if (!c->use_side) return 0;
   EAE_HIP(hipEventRecord(c->ev_join, c->side));
   EAE_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
-  if (c->side2) {
-    EAE_HIP(hipEventRecord(c->ev_join2, c->side2));
-    EAE_HIP(hipStreamWaitEvent(st, c->ev_join2, 0));
+  for (int i = 0; i < c->nx; ++i) {
+    EAE_HIP(hipEventRecord(c->ev_joinx[i], c->sidex[i]));
+    EAE_HIP(hipStreamWaitEvent(st, c->ev_joinx[i], 0));
   }
   return 0;
 }
