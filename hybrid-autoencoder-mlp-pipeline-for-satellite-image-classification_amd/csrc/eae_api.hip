@@ -219,9 +219,13 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   if (e != hipSuccess) { hipFree(c->ws); delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
   c->use_side = getenv("EAE_NO_SIDE_STREAM") == nullptr;
   if (c->use_side) {
-    e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    // side work only feeds the optimizer: lowest priority, so the dependency chain on the caller's stream wins the CUs
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const int side_prio = getenv("EAE_SIDE_PRIO_DEFAULT") ? 0 : prio_lo;
+    e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, side_prio);
     for (int i = 0; i < c->nx && e == hipSuccess; ++i) {
-      e = hipStreamCreateWithFlags(&c->sidex[i], hipStreamNonBlocking);
+      e = hipStreamCreateWithPriority(&c->sidex[i], hipStreamNonBlocking, side_prio);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_joinx[i], hipEventDisableTiming);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sx[i], hipEventDisableTiming);
     }
