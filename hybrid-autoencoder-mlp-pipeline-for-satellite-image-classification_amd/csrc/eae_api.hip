@@ -16,6 +16,10 @@ int eae_set_error(int code, const char* msg) { g_err = msg ? msg : "unknown erro
 extern "C" const char* eae_last_error(void) { return g_err.c_str(); }
 extern "C" int eae_version(void) { return 100; }
 
+// fork/join events only order kernels of THIS device: no timing, and no system-scope fence when they complete (the agent-scope
+// release at the end of every kernel is what makes its results visible to the other streams' kernels)
+static const unsigned EV_FLAGS = hipEventDisableTiming | (getenv("EAE_EVENT_SYSTEM_FENCE") ? 0u : hipEventDisableSystemFence);
+
 namespace {
 
 constexpr float BN_EPS = 1e-5f, BN_MOM = 0.1f;
@@ -226,16 +230,16 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
     e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, side_prio);
     for (int i = 0; i < c->nx && e == hipSuccess; ++i) {
       e = hipStreamCreateWithPriority(&c->sidex[i], hipStreamNonBlocking, side_prio);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_joinx[i], hipEventDisableTiming);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sx[i], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_joinx[i], EV_FLAGS);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sx[i], EV_FLAGS);
     }
-    for (int i = 0; i < eae_ctx::NEV && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_head, hipEventDisableTiming);
+    for (int i = 0; i < eae_ctx::NEV && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_fork[i], EV_FLAGS);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, EV_FLAGS);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_head, EV_FLAGS);
     c->head_side = getenv("EAE_HEAD_MAIN") == nullptr;     // the head only needs z: it runs beside the decoder
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_main, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, EV_FLAGS);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, EV_FLAGS);
     if (e != hipSuccess) { hipFree(c->ws); delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
   }
   *out = c;
