@@ -83,6 +83,12 @@ struct eae_ctx {
   hipStream_t sidex[MAXX] = {};
   hipEvent_t ev_joinx[MAXX] = {}, ev_sx[MAXX] = {};
   float* wscratchx[MAXX] = {};
+  float* wscratch_main = nullptr;
+  // data-parallel hand-off streams: after a gradient step #0 is ordered after gradient tensors 18..37 (classifier, decoder,
+  // dec.fc) and #1 after tensors 8..17 (enc.fc, conv4, conv3); tensors 0..7 are complete when the step's join is reached
+  hipStream_t dp_stream[2] = {nullptr, nullptr};
+  hipEvent_t ev_part[2] = {nullptr, nullptr};
+  bool side_forked = false;        // `side` already waits for the current position of the main stream (no kernel enqueued on main since)
   int side_rr = 0;
   hipStream_t own_main = nullptr;  // capture is not permitted on the legacy default stream: graphs run here, bracketed by events
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -172,6 +178,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
     if (getenv("EAE_ONE_SIDE_STREAM")) c->nx = 0;
   }
   for (int i = 0; i < c->nx; ++i) o_wscrx[i] = carve(c->wscratch_floats * 4);
+  size_t o_wscrm = carve((size_t)512 * 864 * 4);      // conv1 weight gradient (last kernel of the backward, runs on the main stream)
   const int ksplit = (int)(c->K / 128);
   size_t o_fcp = carve((size_t)ksplit * Bm * c->L * 4);
   size_t o_mse = carve(std::max((size_t)eae_edge_tiles((int)Bm, c->H, c->W), (size_t)((Bm * c->H * c->W + 255) / 256)) * 4 * 4);
@@ -210,7 +217,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->d0 = (bf16_t*)(b + o_d0); c->gd0 = (bf16_t*)(b + o_gd0); c->g4 = (bf16_t*)(b + o_g4);
   c->z = (float*)(b + o_z); c->dz = (float*)(b + o_dz); c->dzc = (float*)(b + o_dzc);
   for (int l = 0; l < 7; ++l) { c->coef_f[l] = (float*)(b + o_cf[l]); c->coef_b[l] = (float*)(b + o_cb[l]); }
-  c->stat = (float*)(b + o_stat); c->wscratch = (float*)(b + o_wscr);
+  c->stat = (float*)(b + o_stat); c->wscratch = (float*)(b + o_wscr); c->wscratch_main = (float*)(b + o_wscrm);
   for (int i = 0; i < c->nx; ++i) c->wscratchx[i] = (float*)(b + o_wscrx[i]); c->fcpart = (float*)(b + o_fcp);
   c->msepart = (float*)(b + o_mse); c->cepart = (float*)(b + o_ce); c->headpart = (float*)(b + o_head); c->lossbuf = (float*)(b + o_loss);
   c->pack = b + o_pack; c->descs_dev = (PackDesc*)(b + o_desc);
@@ -223,10 +230,13 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   if (e != hipSuccess) { hipFree(c->ws); delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
   c->use_side = getenv("EAE_NO_SIDE_STREAM") == nullptr;
   if (c->use_side) {
-    // side work only feeds the optimizer: lowest priority, so the dependency chain on the caller's stream wins the CUs
+    // Side work only feeds the optimizer.  Lowest stream priority (EAE_SIDE_PRIO_LOW=1) lets the dependency chain on the
+    // caller's stream win the CUs (-7 us/step at B=512), but it is not the default: whenever only low-priority queues had
+    // work while the caller's stream waited on them through a third stream (the data-parallel step: all-reduce -> Adam) the
+    // step took 1.2-2.3 ms instead of 0.63 (queue scheduling quanta), DESIGN.md section 6.
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    const int side_prio = getenv("EAE_SIDE_PRIO_DEFAULT") ? 0 : prio_lo;
+    const int side_prio = getenv("EAE_SIDE_PRIO_LOW") ? prio_lo : 0;
     e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, side_prio);
     for (int i = 0; i < c->nx && e == hipSuccess; ++i) {
       e = hipStreamCreateWithPriority(&c->sidex[i], hipStreamNonBlocking, side_prio);
@@ -295,6 +305,7 @@ extern "C" int eae_destroy(eae_ctx* c) {
     hipEventDestroy(c->ev_join);
     if (c->ev_head) hipEventDestroy(c->ev_head);
     hipStreamDestroy(c->side);
+    for (int i = 0; i < 2; ++i) if (c->dp_stream[i]) { hipStreamDestroy(c->dp_stream[i]); hipEventDestroy(c->ev_part[i]); }
     for (int i = 0; i < c->nx; ++i)
       if (c->sidex[i]) { hipStreamDestroy(c->sidex[i]); hipEventDestroy(c->ev_joinx[i]); hipEventDestroy(c->ev_sx[i]); }
     if (c->own_main) { hipStreamDestroy(c->own_main); hipEventDestroy(c->ev_in); hipEventDestroy(c->ev_out); }
@@ -519,7 +530,7 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
     // in a gradient step nothing on the main stream reads what this kernel writes (deconv4 bias gradient, loss scalars):
     // it goes to the side stream, which backward_impl joins before the optimizer
     hipStream_t ls = st;
-    if (want_grad) RC(fork_side(c, st, &ls));
+    if (want_grad) { RC(fork_side(c, st, &ls)); c->side_forked = c->use_side; }
     RC(eae_launch_loss_finalize(ls, c->msepart, eae_edge_tiles(B, c->H, c->W), c->cepart, n_ce, io->alpha, numel, B,
                                 want_grad ? c->G + c->poff[33] : nullptr, io->loss_accum, io->loss_last));
   }
@@ -533,7 +544,9 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
   hipStream_t ss;       // side streams: everything that only feeds the optimizer (weight gradients and their reductions)
   float* scr = c->wscratch;
   c->side_rr = 0;
-  RC(fork_side(c, st, &ss));
+  if (c->side_forked && part != 2) ss = c->side;      // forward_impl forked at this very position for the loss finalize
+  else RC(fork_side(c, st, &ss));
+  c->side_forked = false;
   if (part != 2) {
   // ---- classifier weight gradients (partials written by the head kernel)
   if (head) {
@@ -545,7 +558,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     EAE_HIP(hipMemsetAsync(c->G + c->poff[34], 0, (size_t)(c->poff[38] - c->poff[34]) * 4, ss));
   }
   // ---- deconv4: weight gradient, then backward-data into u[2]'s BN+ReLU
-  RC(fork_wgrad(c, st, &ss, &scr));
+  c->side_rr = 1;                // this group stays on `side` (already forked here); the next group starts the round-robin at side #1
   RC(eae_launch_edge_wgrad(ss, SRC3_NHWC4_BF16, c->g4, B, H, W, src_bnrelu(c->u[2], c->coef_f[6]), SRC_BNRELU, scr,
                            c->wscratch_floats, c->G + c->poff[32]));
   {
@@ -599,6 +612,11 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
   }
   }   // part != 2
   if (part == 1) return fold_side2(c);     // the caller may now all-reduce gradient tensors 18..37 behind the side stream
+  if (part == 0 && c->dp_stream[0]) {      // same hand-off without splitting the call: see eae_dp_stream()
+    RC(fold_side2(c));
+    EAE_HIP(hipEventRecord(c->ev_part[0], c->side));
+    EAE_HIP(hipStreamWaitEvent(c->dp_stream[0], c->ev_part[0], 0));
+  }
   // ---- enc.fc: weight/bias gradient and backward-data into y[3]'s BN+ReLU
   {
     FcTnArgs t = FcTnArgs();
@@ -631,11 +649,17 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     a.B = B; a.Hin = Hs; a.Win = Ws;
     RC(eae_launch_deconv_s2(a, cs, cb, SRC_BNBWD, EPI_MASK, st));
     RC(bn_bwd_fin(c, st, i - 1, eae_conv_s2_ntiles(1, B, Hs, Ws), (long long)B * (Hs * 2) * (Ws * 2)));
+    if (i == 2 && part == 0 && c->dp_stream[1]) {     // enc.fc, conv4 and conv3 weight gradients have been enqueued
+      RC(fold_side2(c));
+      EAE_HIP(hipEventRecord(c->ev_part[1], c->side));
+      EAE_HIP(hipStreamWaitEvent(c->dp_stream[1], c->ev_part[1], 0));
+    }
   }
   // ---- conv1 weight gradient
-  RC(fork_wgrad(c, st, &ss, &scr));         // needs coef_b[0]
-  RC(eae_launch_edge_wgrad(ss, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, scr,
-                           c->wscratch_floats, c->G + c->poff[0]));
+  // ---- conv1 weight gradient: nothing is left for the main stream to do, so the last weight gradient runs there (no fork
+  //      latency in the tail of the step) while the side streams drain
+  RC(eae_launch_edge_wgrad(st, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, c->wscratch_main,
+                           512LL * 864, c->G + c->poff[0]));
   RC(join_side(c, st));
   // Biases in front of a BatchNorm have an identically zero gradient (the reference computes ~1e-9 rounding noise);
   // their slots in the gradient arena are zeroed once in eae_bind and never written.
@@ -701,6 +725,16 @@ extern "C" int eae_ae_grad_step_end(eae_ctx* c, void* stream) {
   return rc;
 }
 extern "C" void* eae_side_stream(eae_ctx* c) { return c ? (void*)c->side : nullptr; }
+extern "C" void* eae_dp_stream(eae_ctx* c, int which) {
+  if (!c || !c->use_side || which < 0 || which > 1) return nullptr;
+  if (!c->dp_stream[which]) {
+    if (hipStreamCreateWithFlags(&c->dp_stream[which], hipStreamNonBlocking) != hipSuccess) { c->dp_stream[which] = nullptr; return nullptr; }
+    if (hipEventCreateWithFlags(&c->ev_part[which], EV_FLAGS) != hipSuccess) {
+      hipStreamDestroy(c->dp_stream[which]); c->dp_stream[which] = nullptr; return nullptr;
+    }
+  }
+  return (void*)c->dp_stream[which];
+}
 // optimizer.step() on gradients that are SUMS over `1/grad_scale` replicas (grad_scale = 1/world_size)
 extern "C" int eae_adam_step_scaled(eae_ctx* c, void* stream, float lr, float weight_decay, float grad_scale) {
   if (!c || !c->P || !c->G || !c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: parameter, gradient and moment arenas must be bound");

@@ -42,7 +42,7 @@ int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B
 #undef CASE
   return eae_set_error(-2, "edge_wgrad: combination not instantiated");
 reduce:
-  hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(864 / 4)), dim3(256), 0, st, scratch, nblocks, (long)(864 / 4), dw, 1.0f);
+  hipLaunchKernelGGL(reduce_slices_tall_kernel, dim3((864 / 4 + 3) / 4), dim3(256), 0, st, scratch, nblocks, (long)(864 / 4), dw);
   EAE_LAUNCH_CHECK();
   return 0;
 }

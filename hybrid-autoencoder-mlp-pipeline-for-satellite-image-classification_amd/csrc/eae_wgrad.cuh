@@ -188,3 +188,25 @@ static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_perm_kerne
 }
 
 static inline unsigned reduce_slices_grid(long n4) { return (unsigned)((n4 + 15) / 16); }
+
+// Tall variant for few outputs and many slices (conv1 / deconv4 weight gradients: 216 float4, 512 slices): 4 float4 columns
+// x 64 slice lanes per block -> 4x the blocks and a quarter of the serial loads per thread; fixed summation order.
+static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_tall_kernel(const float* __restrict__ part, int nslices, long n4,
+                                                                                float* __restrict__ out) {
+  __shared__ float4 red[64][4];
+  const int lx = threadIdx.x & 3, ly = threadIdx.x >> 2;
+  const long i = (long)blockIdx.x * 4 + lx;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4)
+    for (int sidx = ly; sidx < nslices; sidx += 64) {
+      float4 v = reinterpret_cast<const float4*>(part)[(long)sidx * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  red[ly][lx] = s;
+  __syncthreads();
+  if (ly == 0 && i < n4) {
+    float4 r = red[0][lx];
+    for (int k = 1; k < 64; ++k) { r.x += red[k][lx].x; r.y += red[k][lx].y; r.z += red[k][lx].z; r.w += red[k][lx].w; }
+    reinterpret_cast<float4*>(out)[i] = r;
+  }
+}

@@ -198,6 +198,12 @@ class AEEngine:
         h = self.lib.eae_side_stream(self.ctx)
         return torch.cuda.ExternalStream(h, device=self.device) if h else None
 
+    def dp_stream(self, which=0):
+        """Engine stream that after every grad_step() is ordered after gradient tensors 18..37 (which=0) or 8..17 (which=1),
+        as a torch ExternalStream."""
+        h = self.lib.eae_dp_stream(self.ctx, int(which))
+        return torch.cuda.ExternalStream(h, device=self.device) if h else None
+
     def train_step(self, x, labels, alpha, lr, head=True, x_hat=None):
         """One iteration of the reference's batch loop (R.md:646-657); the loss is accumulated on the device."""
         io, keep = self._io(x, labels, True, head, alpha, x_hat)

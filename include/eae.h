@@ -91,6 +91,12 @@ int eae_adam_step(eae_ctx* ctx, void* stream, float lr, float weight_decay);
 int eae_ae_grad_step_begin(eae_ctx* ctx, void* stream, const eae_step_io* io);
 int eae_ae_grad_step_end(eae_ctx* ctx, void* stream);
 void* eae_side_stream(eae_ctx* ctx);
+/* The same hand-off without splitting the call (no host gap between the halves): once requested, engine-owned stream `which`
+ * is, after every eae_ae_grad_step, ordered after the completion of gradient tensors 18..37 (which = 0: classifier, decoder,
+ * dec.fc) or 8..17 (which = 1: enc.fc, conv4, conv3); a collective enqueued behind it overlaps the rest of that step's
+ * backward.  Tensors 0..7 are complete on the caller's stream when the call returns.  NULL when side-stream concurrency is
+ * disabled. */
+void* eae_dp_stream(eae_ctx* ctx, int which);
 int eae_adam_step_scaled(eae_ctx* ctx, void* stream, float lr, float weight_decay, float grad_scale);
 /* eae_ae_grad_step + eae_adam_step: one iteration of the reference's batch loop (R.md:642-658). */
 int eae_ae_train_step(eae_ctx* ctx, void* stream, const eae_step_io* io, float lr);
