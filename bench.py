@@ -196,7 +196,8 @@ def main():
                                 "frac_of_hbm_floor": round(step_bytes / (HBM_PEAK_GBS * 1e3) / (ms * 1e3), 4)}
         if not args.no_roofline:
             try:
-                out["roofline"] = kernel_roofline(eng, step, args.batch)
+                # local steps only: the other ranks have left the loop, so no collective may be issued from here
+                out["roofline"] = kernel_roofline(eng, lambda: eng.train_step(x, y, ALPHA, LR), args.batch)
             except Exception as e:  # the headline number must still be printed
                 out["roofline"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
