@@ -361,3 +361,34 @@ def test_config5_shape_256px_latent256_vs_oracle():
         if not c > 0.99:
             bad.append((name, c))
     assert not bad, bad
+
+
+def test_full_size_batch512_properties():
+    """BASELINE config c3 size (B=512), where the oracle is too slow: size-independent properties instead.
+    (1) eval-mode forward is per-image: one B=512 call == eight B=64 calls, bitwise;
+    (2) the gradient is affine in alpha (loss = alpha*MSE + CE): g(35)-g(20) == 1.5*(g(30)-g(20)) within bf16 noise;
+    (3) two identical gradient steps from the same state are bitwise equal (no atomics anywhere)."""
+    import gpu_util as G
+    x, y = gu.make_images(512, 777)
+    xd, yd = _cuda(x), _cuda(y)
+    m = _model()
+    m.eval()
+    eng = _engine(m, max_batch=512)
+    xh, lg, z = eng.forward(xd, labels=yd, train=False, alpha=35.0)
+    torch.cuda.synchronize()
+    for k in range(0, 512, 64):
+        xh_k, lg_k, z_k = eng.forward(xd[k:k + 64].contiguous(), labels=yd[k:k + 64].contiguous(), train=False, alpha=35.0)
+        torch.cuda.synchronize()
+        assert torch.equal(z_k, z[k:k + 64]) and torch.equal(lg_k, lg[k:k + 64]) and torch.equal(xh_k, xh[k:k + 64]), k
+    grads = {}
+    for alpha in (20.0, 30.0, 35.0, 35.0):
+        m2 = _model()
+        e2 = _engine(m2, max_batch=512)
+        e2.grad_step(xd, yd, alpha)
+        torch.cuda.synchronize()
+        g = e2.grads.cpu().numpy().copy()
+        if alpha in grads:
+            assert np.array_equal(grads[alpha], g)              # (3)
+        grads[alpha] = g
+    d35, d30 = grads[35.0] - grads[20.0], grads[30.0] - grads[20.0]
+    assert G.cosine(d35, 1.5 * d30) > 0.999 and G.relmax(d35, 1.5 * d30) < 3e-2, (G.cosine(d35, 1.5 * d30), G.relmax(d35, 1.5 * d30))
