@@ -16,9 +16,10 @@ int launch(const ConvArgs& a, hipStream_t st) {   // NOLINT
   }
   const int Hpos = (KIND == KIND_CONV) ? a.Hin / 2 : a.Hin, Wpos = (KIND == KIND_CONV) ? a.Win / 2 : a.Win;
   const int groups = (a.B + NI - 1) / NI;
-  dim3 grid(groups * (Hpos / TH) * (Wpos / TW), COUT / BN);
+  const int ntiles = groups * (Hpos / TH) * (Wpos / TW);
+  dim3 grid(ntiles * (COUT / BN));        // 1-D: the kernel maps ids to (tile, channel block) XCD-aware
   ConvArgs b = a;
-  b.ntiles = (int)grid.x;
+  b.ntiles = ntiles;
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, b);
   EAE_LAUNCH_CHECK();
   return 0;

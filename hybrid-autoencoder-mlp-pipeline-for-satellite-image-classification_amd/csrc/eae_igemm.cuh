@@ -217,11 +217,22 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT)) void igemm_s2_kernel(
   const int Hout = (KIND == KIND_CONV) ? a.Hin >> 1 : a.Hin * 2, Wout = (KIND == KIND_CONV) ? a.Win >> 1 : a.Win * 2;
   const int Hpos = (KIND == KIND_CONV) ? Hout : a.Hin, Wpos = (KIND == KIND_CONV) ? Wout : a.Win;   // position grid
   const int tiles_x = Wpos / TW, tiles_y = Hpos / TH;
-  int t = blockIdx.x;
+  // Workgroup -> (tile, channel block).  The COUT/BN channel blocks of one tile read the same input patch: they are placed on
+  // the SAME XCD (workgroup ids go round-robin over the 8 XCDs) and next to each other in dispatch order, so the second one
+  // finds the patch in that XCD's L2 instead of fetching it again over the fabric.
+  constexpr int NB = COUT / BN;
+  int tile_id, nblk;
+  {
+    const int bid = blockIdx.x;
+    if (NB == 1) { tile_id = bid; nblk = 0; }
+    else if (a.ntiles % 8 == 0) { const int xcd = bid & 7, idx = bid >> 3; nblk = idx % NB; tile_id = (idx / NB) * 8 + xcd; }
+    else { nblk = bid % NB; tile_id = bid / NB; }
+  }
+  int t = tile_id;
   const int txb = t % tiles_x; t /= tiles_x;
   const int tyb = t % tiles_y; t /= tiles_y;
   const int img0 = t * NI;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = nblk * BN;
   const int iy0 = (KIND == KIND_CONV) ? 2 * tyb * TH - 1 : tyb * TH, ix0 = (KIND == KIND_CONV) ? 2 * txb * TW - 1 : txb * TW;
 
   EAE_STAMP(0);
@@ -426,11 +437,11 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT)) void igemm_s2_kernel(
   if (do_stats) {
     // st1: every accumulator row holds the column sums -> lanes 0..15 (row group 0, register 0)
     // st2: the diagonal element of column j sits in lane 16*(j>>2) + j, register j&3
-    float* sp = a.stat_part + (size_t)(n0 + wave * 16 + (lane & 15)) * a.ntiles + blockIdx.x;
+    float* sp = a.stat_part + (size_t)(n0 + wave * 16 + (lane & 15)) * a.ntiles + tile_id;
     if (tg == 0) sp[0] = st1[0];
     if (tg == tq) { float d = tp == 0 ? st2[0] : tp == 1 ? st2[1] : tp == 2 ? st2[2] : st2[3]; sp[(size_t)COUT * a.ntiles] = d; }
   }
-  epi.end(a, red, n0, blockIdx.x);
+  epi.end(a, red, n0, tile_id);
   EAE_STAMP(7);
   EAE_STAMP_WG(1);
 }
