@@ -21,7 +21,7 @@ struct WgradArgs {
   SrcDesc small, big;
   float* part;            // [nslices][9][CS][CB]
   int B, Hs, Ws;          // small-map spatial size (big map = 2Hs x 2Ws)
-  int tiles_per_block, ntiles;
+  int tiles_per_block, ntiles, nslices;
 };
 
 constexpr int S_STRIDE = 72;   // bf16 elements per staged S row: 64 channels + 8 pad (144 B)
@@ -36,7 +36,17 @@ __global__ __launch_bounds__(256) void wgrad_s2_kernel(WgradArgs a) {
   bf16_t* patch = smem;                          // [NPIX][PIX_STRIDE]
   bf16_t* sl = smem + NPIX * PIX_STRIDE;         // [128][S_STRIDE]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cs0 = (blockIdx.y / (CB / 32)) * 64, cb0 = (blockIdx.y % (CB / 32)) * 32;
+  // workgroup -> (position slice, output block): the (CS/64)*(CB/32) output blocks of one slice read the same tiles, so they
+  // sit on the same XCD, adjacent in dispatch order (ids go round-robin over the 8 XCDs), and share them through that L2
+  constexpr int NBLK = (CS / 64) * (CB / 32);
+  int slice, oblk;
+  {
+    const int bid = blockIdx.x;
+    if (NBLK == 1) { slice = bid; oblk = 0; }
+    else if (a.nslices % 8 == 0) { const int xcd = bid & 7, idx = bid >> 3; oblk = idx % NBLK; slice = (idx / NBLK) * 8 + xcd; }
+    else { oblk = bid % NBLK; slice = bid / NBLK; }
+  }
+  const int cs0 = (oblk / (CB / 32)) * 64, cb0 = (oblk % (CB / 32)) * 32;
   const int Hb = a.Hs * 2, Wb = a.Ws * 2;
   const int tiles_x = a.Ws / TW, tiles_y = a.Hs / TH;
   const int kgs4 = tid & 3, kgs8 = tid & 7;
@@ -52,7 +62,7 @@ __global__ __launch_bounds__(256) void wgrad_s2_kernel(WgradArgs a) {
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
 
   for (int ti = 0; ti < a.tiles_per_block; ++ti) {
-    int t = blockIdx.x * a.tiles_per_block + ti;
+    int t = slice * a.tiles_per_block + ti;
     if (t >= a.ntiles) break;
     const int txb = t % tiles_x; t /= tiles_x;
     const int tyb = t % tiles_y; t /= tiles_y;
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(256) void wgrad_s2_kernel(WgradArgs a) {
   }
   // ---- store the partial as [tap][cs][cb] (16 consecutive cb per lane group -> 64-byte segments); the reduce kernel
   //      permutes into the reference layout [cs][cb][3][3]
-  float* out = a.part + (size_t)blockIdx.x * ((size_t)CS * CB * 9);
+  float* out = a.part + (size_t)slice * ((size_t)CS * CB * 9);
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll

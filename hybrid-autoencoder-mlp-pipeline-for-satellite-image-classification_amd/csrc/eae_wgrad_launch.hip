@@ -17,6 +17,7 @@ int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_fl
   a.tiles_per_block = (ntiles + slices - 1) / slices;
   slices = (ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
   a.part = scratch;
+  a.nslices = slices;
   auto kern = wgrad_s2_kernel<CS, CB, TW, TH, NI, SM, BM>;
   constexpr size_t smem = wgrad_smem<TW, TH, NI>();
   static bool done = false;
@@ -24,7 +25,7 @@ int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_fl
     EAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(slices, nblk), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(slices * nblk), dim3(256), smem, st, a);
   EAE_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_slices_perm_kernel, dim3(reduce_slices_grid(sz / 4)), dim3(256), 0, st, scratch, slices, CS, CB, dw);
   EAE_LAUNCH_CHECK();
