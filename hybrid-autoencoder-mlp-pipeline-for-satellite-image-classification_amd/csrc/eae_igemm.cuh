@@ -376,8 +376,12 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT)) void igemm_s2_kernel(
   EAE_STAMP(4);
   __syncthreads();
   EAE_STAMP(5);
+  // The transposed kind handles its two horizontal phases (px = 0, 1) in ONE pass: tile row 2*m + px, so consecutive rows are
+  // horizontally adjacent output pixels and the stores (and the reads of the previous layer's tensor in the mask epilogue)
+  // cover whole 128-byte lines instead of every other 64 bytes (conv2 backward-data: 144 -> ~105 MB of HBM traffic per launch).
+  constexpr int PHG = (KIND == KIND_CONV) ? 1 : 2, R2 = P * PHG;
   bf16_t* tile = smem;
-  float* red = reinterpret_cast<float*>(smem + P * TS);
+  float* red = reinterpret_cast<float*>(smem + R2 * TS);
 #ifdef EAE_NO_MFMA_STATS
   TileEpilogue<COUT, BN, EPI, true> epi;
 #else
@@ -402,36 +406,41 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT)) void igemm_s2_kernel(
   for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
   const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
 #pragma unroll
-  for (int ph = 0; ph < NPH; ++ph) {
-    if (ph) __syncthreads();
+  for (int pass = 0; pass < NPH / PHG; ++pass) {
+    if (pass) __syncthreads();
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-      int row = (wm * MT + mi) * 16 + (lane & 15);
-      uint2 w2;
-      w2.x = pk2((f32x2){acc[ph][mi][0] + bv.x, acc[ph][mi][1] + bv.y});
-      w2.y = pk2((f32x2){acc[ph][mi][2] + bv.z, acc[ph][mi][3] + bv.w});
-      if (NI > 1 && img0 + row / (TH * TW) >= B) w2 = make_uint2(0, 0);   // images past the batch must not enter the statistics
-      *reinterpret_cast<uint2*>(tile + row * TS + wn * 16 + kgl * 4) = w2;
+    for (int px = 0; px < PHG; ++px) {
+      const int ph = pass * PHG + px;
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        int row = (wm * MT + mi) * 16 + (lane & 15);
+        uint2 w2;
+        w2.x = pk2((f32x2){acc[ph][mi][0] + bv.x, acc[ph][mi][1] + bv.y});
+        w2.y = pk2((f32x2){acc[ph][mi][2] + bv.z, acc[ph][mi][3] + bv.w});
+        if (NI > 1 && img0 + row / (TH * TW) >= B) w2 = make_uint2(0, 0);   // images past the batch must not enter the statistics
+        *reinterpret_cast<uint2*>(tile + (row * PHG + px) * TS + wn * 16 + kgl * 4) = w2;
+      }
     }
     __syncthreads();
     if (do_stats) {
 #pragma unroll
-      for (int ks = 0; ks < P / 32; ++ks) {
+      for (int ks = 0; ks < R2 / 32; ++ks) {
         const bf16_t* lo = tile + (ks * 32 + 8 * tg + tq) * TS + wave * 16 + 4 * tp;
         bf16x8 fr = tr_frag(lo, lo + 4 * TS);
         st1 = mfma16(ones, fr, st1);
         st2 = mfma16(fr, fr, st2);
       }
     }
-    auto rowmap = [=](int row) -> long {
+    auto rowmap = [=](int row2) -> long {
+      const int row = row2 / PHG, px = row2 % PHG;
       int img = row / (TH * TW), ty = (row / TW) % TH, tx = row % TW;
       int n = img0 + img;
       if (n >= B) return -1;
-      int oy = (KIND == KIND_CONV) ? tyb * TH + ty : 2 * (tyb * TH + ty) + (ph >> 1);
-      int ox = (KIND == KIND_CONV) ? txb * TW + tx : 2 * (txb * TW + tx) + (ph & 1);
+      int oy = (KIND == KIND_CONV) ? tyb * TH + ty : 2 * (tyb * TH + ty) + pass;
+      int ox = (KIND == KIND_CONV) ? txb * TW + tx : 2 * (txb * TW + tx) + px;
       return (((long)n * Hout + oy) * Wout + ox) * COUT;
     };
-    epi.rows(a, tile, n0, P, rowmap);
+    epi.rows(a, tile, n0, R2, rowmap);
   }
   EAE_STAMP(6);
   if (do_stats) {
@@ -450,6 +459,6 @@ template <int KIND, int BN, int TW, int TH, int NI>
 constexpr size_t igemm_smem() {
   using G = Geo<KIND, TW, TH, NI>;
   constexpr size_t patch = (size_t)NI * G::PH * G::RS * 2;
-  constexpr size_t tile = (size_t)G::P * (BN + 8) * 2 + (size_t)2 * (256 / (BN / 8)) * BN * 4;
+  constexpr size_t tile = (size_t)G::P * (KIND == KIND_CONV ? 1 : 2) * (BN + 8) * 2 + (size_t)2 * (256 / (BN / 8)) * BN * 4;
   return (patch > tile ? patch : tile) + EAE_LDS_SLACK;
 }
