@@ -88,6 +88,13 @@ struct eae_ctx {
   // dec.fc) and #1 after tensors 8..17 (enc.fc, conv4, conv3); tensors 0..7 are complete when the step's join is reached
   hipStream_t dp_stream[2] = {nullptr, nullptr};
   hipEvent_t ev_part[2] = {nullptr, nullptr};
+  // folded BatchNorm finalize (forward): fixed-point statistics accumulators per BN layer
+  unsigned long long* accf[7] = {};
+  int acc_copies[7] = {};
+  uint8_t* acc_base = nullptr;
+  size_t acc_bytes = 0;
+  bool acc_clean = false;          // all zero (cleared by the engine's own Adam launch or at creation)
+  bool fold_fwd = true;
   bool side_forked = false;        // `side` already waits for the current position of the main stream (no kernel enqueued on main since)
   int side_rr = 0;
   hipStream_t own_main = nullptr;  // capture is not permitted on the legacy default stream: graphs run here, bracketed by events
@@ -178,7 +185,22 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
     if (getenv("EAE_ONE_SIDE_STREAM")) c->nx = 0;
   }
   for (int i = 0; i < c->nx; ++i) o_wscrx[i] = carve(c->wscratch_floats * 4);
-  size_t o_wscrm = carve((size_t)512 * 864 * 4);      // conv1 weight gradient (last kernel of the backward, runs on the main stream)
+  size_t o_wscrm = carve((size_t)512 * 864 * 4);
+  size_t o_acc[7], acc_total = 0;
+  {
+    const int Bi = (int)Bm;
+    const int nt[7] = {eae_edge_tiles(Bi, c->H, c->W), eae_conv_s2_ntiles(0, Bi, c->H / 2, c->W / 2), eae_conv_s2_ntiles(0, Bi, c->H / 4, c->W / 4),
+                       eae_conv_s2_ntiles(0, Bi, c->H / 8, c->W / 8), eae_conv_s2_ntiles(1, Bi, c->H / 16, c->W / 16),
+                       eae_conv_s2_ntiles(1, Bi, c->H / 8, c->W / 8), eae_conv_s2_ntiles(1, Bi, c->H / 4, c->W / 4)};
+    for (int l = 0; l < 7; ++l) {
+      int cp = 8;
+      while (cp < 64 && cp * 2 * 16 <= nt[l]) cp *= 2;        // about one accumulator set per 16 producer workgroups
+      c->acc_copies[l] = cp;
+      o_acc[l] = acc_total;
+      acc_total += (size_t)cp * 2 * BN_C[l] * 8;
+    }
+  }
+  size_t o_accb = carve(acc_total);      // conv1 weight gradient (last kernel of the backward, runs on the main stream)
   const int ksplit = (int)(c->K / 128);
   size_t o_fcp = carve((size_t)ksplit * Bm * c->L * 4);
   size_t o_mse = carve(std::max((size_t)eae_edge_tiles((int)Bm, c->H, c->W), (size_t)((Bm * c->H * c->W + 255) / 256)) * 4 * 4);
@@ -218,6 +240,8 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->z = (float*)(b + o_z); c->dz = (float*)(b + o_dz); c->dzc = (float*)(b + o_dzc);
   for (int l = 0; l < 7; ++l) { c->coef_f[l] = (float*)(b + o_cf[l]); c->coef_b[l] = (float*)(b + o_cb[l]); }
   c->stat = (float*)(b + o_stat); c->wscratch = (float*)(b + o_wscr); c->wscratch_main = (float*)(b + o_wscrm);
+  c->acc_base = b + o_accb; c->acc_bytes = (acc_total + 15) & ~(size_t)15;
+  for (int l = 0; l < 7; ++l) c->accf[l] = (unsigned long long*)(b + o_accb + o_acc[l]);
   for (int i = 0; i < c->nx; ++i) c->wscratchx[i] = (float*)(b + o_wscrx[i]); c->fcpart = (float*)(b + o_fcp);
   c->msepart = (float*)(b + o_mse); c->cepart = (float*)(b + o_ce); c->headpart = (float*)(b + o_head); c->lossbuf = (float*)(b + o_loss);
   c->pack = b + o_pack; c->descs_dev = (PackDesc*)(b + o_desc);
@@ -227,6 +251,9 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->use_graph = getenv("EAE_GRAPH") != nullptr && getenv("EAE_NO_GRAPH") == nullptr;
   e = hipMemcpy(c->descs_dev, descs.data(), descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(c->g4, 0, Bm * (size_t)c->H * c->W * 4 * 2);
+  if (e == hipSuccess) e = hipMemset(c->acc_base, 0, c->acc_bytes);
+  c->acc_clean = true;
+  c->fold_fwd = getenv("EAE_NO_FOLD_FWD") == nullptr;
   if (e != hipSuccess) { hipFree(c->ws); delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
   c->use_side = getenv("EAE_NO_SIDE_STREAM") == nullptr;
   if (c->use_side) {
@@ -391,7 +418,27 @@ SrcDesc src_bnrelu(const bf16_t* y, const float* coef) { SrcDesc s; s.p0 = y; s.
 SrcDesc src_bnbwd(const bf16_t* g, const bf16_t* y, const float* coef) { SrcDesc s; s.p0 = g; s.p1 = y; s.coef = coef; return s; }
 SrcDesc src_f32(const float* p) { SrcDesc s; s.p0 = reinterpret_cast<const bf16_t*>(p); s.p1 = nullptr; s.coef = nullptr; return s; }
 
+constexpr float ACC_SCALE_FWD = 16777216.f;      // 2^24: sums of y and y^2 over <= 2^21 elements of |y| <~ 1e3 stay far below 2^63
+
+// producer side of the folded forward finalize of BN layer l
+void fold_producer(eae_ctx* c, ConvArgs& a, int l, bool train) {
+  if (!train || !c->fold_fwd) return;
+  a.bacc.acc = c->accf[l]; a.bacc.copies = c->acc_copies[l]; a.bacc.scale = ACC_SCALE_FWD;
+  a.stat_part = nullptr;
+}
+// consumer side: coefficient table of BN layer l from its accumulators
+void fold_consumer(eae_ctx* c, BnFold& f, int l, long long count, bool train) {
+  f = BnFold();
+  if (!train || !c->fold_fwd) return;
+  f.acc = c->accf[l]; f.copies = c->acc_copies[l]; f.inv_scale = 1.0f / ACC_SCALE_FWD; f.count = (float)count;
+  f.momentum = BN_MOM; f.eps = BN_EPS;
+  f.gamma = c->P + c->poff[BN_GAMMA_IDX[l]]; f.beta = c->P + c->poff[BN_GAMMA_IDX[l] + 1];
+  f.rm = c->bnrun + c->bnoff[2 * l]; f.rv = c->bnrun + c->bnoff[2 * l + 1]; f.nbt = c->nbt ? c->nbt + l : nullptr;
+  f.coef_out = c->coef_f[l];
+}
+
 int bn_fwd_finalize(eae_ctx* c, hipStream_t st, int l, int ntiles, long long count, bool train) {
+  if (train && c->fold_fwd) return 0;       // folded into the producer (accumulators) and the next kernel (prologue)
   const float* gamma = c->P + c->poff[BN_GAMMA_IDX[l]];
   const float* beta = c->P + c->poff[BN_GAMMA_IDX[l] + 1];
   float* rm = c->bnrun + c->bnoff[2 * l];
@@ -414,6 +461,7 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
     a.c = ConvArgs();
     a.c.wpack = (const bf16_t*)(c->pack + c->pk_c1); a.c.bias = c->P + c->poff[1]; a.c.out = c->y[0];
     a.c.stat_part = train ? c->stat : nullptr; a.c.B = B;
+    fold_producer(c, a.c, 0, train);
     RC(eae_launch_edge_conv(st, SRC3_NCHW_F32, EPI_FWD, a));
     RC(bn_fwd_finalize(c, st, 0, eae_edge_tiles(B, H, W), (long long)B * (H / 2) * (W / 2), train));
   }
@@ -423,6 +471,8 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
     a.wpack = (const bf16_t*)(c->pack + c->pk_p1[i - 1]); a.bias = c->P + c->poff[4 * i + 1]; a.out = c->y[i];
     a.stat_part = train ? c->stat : nullptr;
     a.B = B; a.Hin = H >> i; a.Win = W >> i;
+    fold_producer(c, a, i, train);
+    fold_consumer(c, a.fold, i - 1, (long long)B * a.Hin * a.Win, train);
     const bool prof = c->prof_on && i == 1 && c->prof_n < eae_ctx::PROF_RING;
     if (prof) EAE_HIP(hipEventRecord(c->prof_ev[3 * c->prof_n], st));
     RC(eae_launch_conv_s2(a, ENC_C[i], ENC_C[i + 1], SRC_BNRELU, EPI_FWD, st));
@@ -437,6 +487,7 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
   f.a = src_bnrelu(c->y[3], c->coef_f[3]);
   f.w = (const bf16_t*)(c->pack + c->pk_we1);
   f.M = B; f.N = c->L; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
+  fold_consumer(c, f.fold, 3, (long long)B * c->Pn, train);
   const int ksplit = (int)(c->K / 128);
   RC(eae_launch_fc_nt(st, f, SRC_BNRELU, FCE_PARTIAL, ksplit));
   RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, c->P + c->poff[17], nullptr, nullptr, c->z));
@@ -465,6 +516,8 @@ int run_decoder(eae_ctx* c, hipStream_t st, const float* z, int B, bool train, c
     a.wpack = (const bf16_t*)(c->pack + c->pk_p2[3 + i]); a.bias = c->P + c->poff[21 + 4 * i]; a.out = c->u[i];
     a.stat_part = train ? c->stat : nullptr;
     a.B = B; a.Hin = H >> (4 - i); a.Win = W >> (4 - i);
+    fold_producer(c, a, 4 + i, train);
+    if (i > 0) fold_consumer(c, a.fold, 3 + i, (long long)B * a.Hin * a.Win, train);
     RC(eae_launch_deconv_s2(a, cin[i], cin[i] / 2, i == 0 ? SRC_RAW : SRC_BNRELU, EPI_FWD, st));
     RC(bn_fwd_finalize(c, st, 4 + i, eae_conv_s2_ntiles(1, B, a.Hin, a.Win), (long long)B * (a.Hin * 2) * (a.Win * 2), train));
   }
@@ -473,6 +526,7 @@ int run_decoder(eae_ctx* c, hipStream_t st, const float* z, int B, bool train, c
   d.wjoint = (const bf16_t*)(c->pack + c->pk_d4j); d.bias = c->P + c->poff[33];
   d.x = target; d.x_hat = x_hat; d.g4 = want_grad ? c->g4 : nullptr; d.loss_part = (want_loss || want_grad) ? c->msepart : nullptr;
   d.gscale = gscale; d.B = B; d.Hin = H / 2; d.Win = W / 2;
+  fold_consumer(c, d.fold, 6, (long long)B * (H / 2) * (W / 2), train);
   RC(eae_launch_deconv4_loss(st, SRC_BNRELU, d));
   return 0;
 }
@@ -505,6 +559,10 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
   const bool train = io->train != 0;
   c->fwd_ready = train; c->fwd_B = B; c->fwd_head = io->head; c->fwd_x = io->x;
   RC(ensure_packed(c, st));
+  if (train && c->fold_fwd) {
+    if (!c->acc_clean) EAE_HIP(hipMemsetAsync(c->acc_base, 0, c->acc_bytes, st));
+    c->acc_clean = false;
+  }
   RC(run_encoder(c, st, io->x, B, train));
   const double numel = (double)B * 3.0 * c->H * c->W;
   const float gscale = (float)(2.0 * io->alpha / numel);
@@ -703,8 +761,9 @@ extern "C" int eae_ae_grad_step(eae_ctx* c, void* stream, const eae_step_io* io)
 extern "C" int eae_adam_step(eae_ctx* c, void* stream, float lr, float weight_decay) {
   if (!c || !c->P || !c->G || !c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: parameter, gradient and moment arenas must be bound");
   c->adam_step += 1;
-  RC(eae_launch_adam((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step));
-  c->packed = false;
+  RC(eae_launch_adam_scaled((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step, 1.0f,
+                            c->acc_base, (long long)c->acc_bytes));
+  c->packed = false; c->acc_clean = true;
   return 0;
 }
 
@@ -739,8 +798,9 @@ extern "C" void* eae_dp_stream(eae_ctx* c, int which) {
 extern "C" int eae_adam_step_scaled(eae_ctx* c, void* stream, float lr, float weight_decay, float grad_scale) {
   if (!c || !c->P || !c->G || !c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: parameter, gradient and moment arenas must be bound");
   c->adam_step += 1;
-  RC(eae_launch_adam_scaled((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step, grad_scale));
-  c->packed = false;
+  RC(eae_launch_adam_scaled((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step, grad_scale,
+                            c->acc_base, (long long)c->acc_bytes));
+  c->packed = false; c->acc_clean = true;
   return 0;
 }
 
@@ -772,8 +832,9 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
   if (!ent) {      // plain eager step: Adam takes its bias-correction scalars by value (one launch less on the critical path)
     int rc = forward_impl(c, st, io, true);
     if (!rc) rc = backward_impl(c, st, io);
-    if (!rc) rc = eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f);
-    c->packed = false;
+    if (!rc) rc = eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f,
+                                         c->acc_base, (long long)c->acc_bytes);
+    c->packed = false; c->acc_clean = (rc == 0);
     return rc;
   }
   RC(eae_launch_set_dyn(st, c->dyn, lr, 0.9, 0.999, 0.0, c->adam_step));

@@ -144,4 +144,66 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* row_ptr_lo, const bf16_t
 // reproduced with a register-only victim; the same source built with this attribute is immune).
 #define EAE_NO_PK __attribute__((target("no-packed-fp32-ops")))
 
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm finalize without a kernel of its own (every dependent launch costs ~6 us on this part).
+//   producer: instead of one partial row per workgroup it adds its per-channel sums, converted to FIXED POINT, into one of
+//             `copies` accumulator sets [copies][2][C] with 64-bit integer atomics (integer addition is associative: the result
+//             does not depend on arrival order, so this stays bitwise reproducible; `copies` sets keep the contention low);
+//   consumer: every workgroup of the NEXT kernel sums the copies for all C channels in its prologue (<= 64*2*C 8-byte loads
+//             over 256 threads) and builds the coefficient table in LDS; workgroup 0 also stores the table for the kernels
+//             that need it later and updates the running statistics.
+// ---------------------------------------------------------------------------------------------------------------
+struct BnAcc {
+  unsigned long long* acc;   // [copies][2][C]; zero before the producer runs; nullptr: per-tile partials + finalize kernel
+  int copies;                // power of two
+  float scale;               // fixed-point scale
+};
+struct BnFold {
+  const unsigned long long* acc;   // nullptr: the coefficients come from SrcDesc::coef
+  int copies;
+  float inv_scale, count, momentum, eps;
+  const float* gamma; const float* beta;
+  float* rm; float* rv; long long* nbt;
+  float* coef_out;           // [4][C]: s, t, mean, invstd
+};
+__device__ __forceinline__ void bn_acc_add(const BnAcc& b, int C, int tile_id, int which, int ch, float v) {
+  unsigned long long* p = b.acc + ((size_t)(tile_id & (b.copies - 1)) * 2 + which) * C + ch;
+  __hip_atomic_fetch_add(p, (unsigned long long)(long long)llrintf(v * b.scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// All 256 threads of the workgroup.  table = LDS float [4][C]; red = LDS long long [2][256] (may alias any idle buffer).
+template <int C>
+__device__ __forceinline__ void bn_fold_fwd(const BnFold& f, float* table, long long* red, bool writer) {
+  static_assert(C <= 256 && 256 % C == 0, "channel count");
+  constexpr int G = 256 / C;
+  const int tid = threadIdx.x, ch = tid % C, grp = tid / C;
+  long long s1 = 0, s2 = 0;
+  for (int k = grp; k < f.copies; k += G) {
+    s1 += (long long)f.acc[((size_t)k * 2 + 0) * C + ch];
+    s2 += (long long)f.acc[((size_t)k * 2 + 1) * C + ch];
+  }
+  red[tid] = s1; red[256 + tid] = s2;
+  __syncthreads();
+  if (grp == 0) {
+#pragma unroll
+    for (int g = 1; g < G; ++g) { s1 += red[g * C + ch]; s2 += red[256 + g * C + ch]; }
+    const double a = (double)s1 * (double)f.inv_scale, b = (double)s2 * (double)f.inv_scale;
+    const double mean = a / f.count;
+    double var = b / f.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = 1.0f / sqrtf((float)var + f.eps);
+    const float s = f.gamma[ch] * invstd, t = f.beta[ch] - (float)mean * s;
+    table[ch] = s; table[C + ch] = t; table[2 * C + ch] = (float)mean; table[3 * C + ch] = invstd;
+    if (writer) {
+      f.coef_out[ch] = s; f.coef_out[C + ch] = t; f.coef_out[2 * C + ch] = (float)mean; f.coef_out[3 * C + ch] = invstd;
+      if (f.rm) {
+        const double unb = f.count > 1.f ? var * (double)f.count / ((double)f.count - 1.0) : var;
+        f.rm[ch] = (1.f - f.momentum) * f.rm[ch] + f.momentum * (float)mean;
+        f.rv[ch] = (1.f - f.momentum) * f.rv[ch] + f.momentum * (float)unb;
+      }
+      if (f.nbt && ch == 0) *f.nbt += 1;
+    }
+  }
+  __syncthreads();
+}
+
 #define EAE_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return eae_set_error(-3, hipGetErrorString(e__)); } while (0)

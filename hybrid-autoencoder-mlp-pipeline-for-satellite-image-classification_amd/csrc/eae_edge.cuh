@@ -258,6 +258,7 @@ struct Deconv4Args {
   float* loss_part;        // [ntiles][4]: sum diff^2, sum g (co = 0,1,2)   or nullptr
   float gscale;
   int B, Hin, Win;
+  BnFold fold;             // BNRELU source: coefficient table of deconv3's BatchNorm from its accumulators
 };
 
 template <int SRC>
@@ -278,7 +279,6 @@ __global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
   const int iy0 = tyb * E_TH, ix0 = txb * E_TW;
   const int kgs = tid & 3, kgl = lane >> 4;
   ChanCoef<SRC> cc;
-  cc.load(a.src.coef, 32, kgs * 8);
   RawPiece<SRC> raw[NPA];
   bool val[NPA];
 #pragma unroll
@@ -290,6 +290,15 @@ __global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
     val[i] = (pix < NPIX) && (iy < a.Hin) && (ix < a.Win);
     size_t off = (((size_t)n * a.Hin + iy) * a.Win + ix) * 32 + kgs * 8;
     load_piece<SRC>(a.src, off, val[i], raw[i]);
+  }
+  {   // coefficient table of the 32-channel source layer (folded BatchNorm finalize) while the loads are in flight
+    __shared__ float coef_tab[4 * 32];
+    const float* coefp = a.src.coef;
+    if (SRC == SRC_BNRELU && a.fold.acc != nullptr) {
+      bn_fold_fwd<32>(a.fold, coef_tab, reinterpret_cast<long long*>(sl), blockIdx.x == 0);
+      coefp = coef_tab;
+    }
+    cc.load(coefp, 32, kgs * 8);
   }
 #pragma unroll
   for (int i = 0; i < NPA; ++i) {

@@ -20,6 +20,7 @@ struct FcNtArgs {
   int klen;                // K-range per grid.z slice (multiple of 64)
   float* part;             // FCE_PARTIAL
   ConvArgs c;              // FCE_BIAS_BF16 / FCE_MASK: out, bias ([N]), stat_part, yprev, prev_coef ([4][256])
+  BnFold fold;             // BNRELU source: coefficient table of the 256-channel source layer from its accumulators
 };
 
 constexpr int FC_KC = 64;
@@ -58,6 +59,12 @@ __global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs a) {
   f32x4 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __shared__ float coef_tab[(AMODE == SRC_BNRELU) ? 4 * 256 : 4];
+  const float* coefp = a.a.coef;
+  if (AMODE == SRC_BNRELU && a.fold.acc != nullptr) {
+    bn_fold_fwd<256>(a.fold, coef_tab, reinterpret_cast<long long*>(red), blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+    coefp = coef_tab;
+  }
   for (int k0 = kbeg; k0 < kbeg + a.klen; k0 += FC_KC) {
     if (k0 != kbeg) __syncthreads();
     uint4 av[4], wv[2];
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs a) {
     for (int i = 0; i < 4; ++i) {
       int row = (tid + i * 256) >> 3;
       int k = k0 + kg8 * 8;
-      av[i] = fc_load_a<AMODE>(a.a, (size_t)(m0 + row) * a.K + k, (m0 + row) < a.M, a.a.coef, k & 255);
+      av[i] = fc_load_a<AMODE>(a.a, (size_t)(m0 + row) * a.K + k, (m0 + row) < a.M, coefp, k & 255);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {

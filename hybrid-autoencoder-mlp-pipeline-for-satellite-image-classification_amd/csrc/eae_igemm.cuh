@@ -32,6 +32,8 @@ struct ConvArgs {
   const bf16_t* yprev;     // EPI_MASK: raw pre-BN tensor at the output positions
   const float* prev_coef;  // EPI_MASK: [4][COUT] s,t,mean,invstd of that BN
   int B, Hin, Win;         // input spatial size (conv: out = Hin/2; deconv: out = 2*Hin)
+  BnAcc bacc;              // statistics go to fixed-point accumulators instead of stat_part (finalize folded into the consumer)
+  BnFold fold;             // SRC_BNRELU: build the source layer's coefficient table from its accumulators
 #ifdef EAE_STAMPS
   unsigned long long* dbg; // diagnostic build only: s_memtime stamps of workgroup `dbg_block`, wave 0
   int dbg_block;
@@ -124,7 +126,7 @@ struct TileEpilogue {
   }
   // deterministic reduction over the RPP row-groups that share a channel chunk; red = [2][RPP][BN] floats of LDS
   __device__ __forceinline__ void end(const ConvArgs& a, float* red, int n0, int tile_id) {
-    if (EPI == EPI_PLAIN || a.stat_part == nullptr || (EPI == EPI_FWD && !VALU_STATS)) return;
+    if (EPI == EPI_PLAIN || (a.stat_part == nullptr && a.bacc.acc == nullptr) || (EPI == EPI_FWD && !VALU_STATS)) return;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -137,7 +139,8 @@ struct TileEpilogue {
       int which = tid / BN, ch = tid % BN;
       float acc = 0.f;
       for (int r = 0; r < RPP; ++r) acc += red[(which * RPP + r) * BN + ch];
-      a.stat_part[((size_t)which * COUT + n0 + ch) * a.ntiles + tile_id] = acc;
+      if (a.bacc.acc) bn_acc_add(a.bacc, COUT, tile_id, which, n0 + ch, acc);
+      else a.stat_part[((size_t)which * COUT + n0 + ch) * a.ntiles + tile_id] = acc;
     }
   }
 };
@@ -285,22 +288,29 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT)) void igemm_s2_kernel(
   ChanCoef<SRC> cc;
   // prefetch requests are issued in NOFF slices, one after each offset's MFMA group, so that the vector-memory pipe
   // (the 64 B/clk L1 path is the scarce resource of the multi-chunk layers) drains while the matrix pipe works
-  auto issue_slice = [&](int chunk, int o) {
-    if (o == 0) cc.load(a.src.coef, CIN, chunk * 32 + kgs * 8);
+  __shared__ float coef_tab[(SRC == SRC_BNRELU) ? 4 * CIN : 4];
+  const float* coefp = a.src.coef;
+  auto issue_slice = [&](int chunk, int o, bool with_coef = true) {
+    if (o == 0 && with_coef) cc.load(coefp, CIN, chunk * 32 + kgs * 8);
 #pragma unroll
     for (int i = 0; i < NPA; ++i)
       if (i % G::NOFF == o) load_piece_b<SRC>(rs, val[i] ? boff[i] + chunk * 64 : OOB_OFF, raw[i]);
   };
-  auto issue = [&](int chunk) {
+  auto issue = [&](int chunk, bool with_coef) {
 #pragma unroll
-    for (int o = 0; o < G::NOFF; ++o) issue_slice(chunk, o);
+    for (int o = 0; o < G::NOFF; ++o) issue_slice(chunk, o, with_coef);
   };
   auto load_w = [&](int chunk) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) wf[tap] = *reinterpret_cast<const bf16x8*>(wrow + tap * CIN + chunk * 32);
   };
   load_w(0);
-  issue(0);
+  issue(0, false);          // the first chunk's loads fly while the coefficient table is being built
+  if (SRC == SRC_BNRELU && a.fold.acc != nullptr) {
+    bn_fold_fwd<CIN>(a.fold, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0);
+    coefp = coef_tab;
+  }
+  cc.load(coefp, CIN, kgs * 8);
 #pragma unroll
   for (int chunk = 0; chunk < NC; ++chunk) {
     EAE_STAMP(8 + chunk * 4 + 0);
@@ -398,7 +408,7 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT)) void igemm_s2_kernel(
 #ifdef EAE_NO_MFMA_STATS
   const bool do_stats = false;
 #else
-  const bool do_stats = (EPI == EPI_FWD) && a.stat_part != nullptr && wave < BN / 16;
+  const bool do_stats = (EPI == EPI_FWD) && (a.stat_part != nullptr || a.bacc.acc != nullptr) && wave < BN / 16;
 #endif
   f32x4 st1 = (f32x4){0.f, 0.f, 0.f, 0.f}, st2 = (f32x4){0.f, 0.f, 0.f, 0.f};
   bf16x8 ones;
@@ -446,9 +456,15 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT)) void igemm_s2_kernel(
   if (do_stats) {
     // st1: every accumulator row holds the column sums -> lanes 0..15 (row group 0, register 0)
     // st2: the diagonal element of column j sits in lane 16*(j>>2) + j, register j&3
-    float* sp = a.stat_part + (size_t)(n0 + wave * 16 + (lane & 15)) * a.ntiles + tile_id;
-    if (tg == 0) sp[0] = st1[0];
-    if (tg == tq) { float d = tp == 0 ? st2[0] : tp == 1 ? st2[1] : tp == 2 ? st2[2] : st2[3]; sp[(size_t)COUT * a.ntiles] = d; }
+    const float d2 = tp == 0 ? st2[0] : tp == 1 ? st2[1] : tp == 2 ? st2[2] : st2[3];
+    if (a.bacc.acc) {
+      if (tg == 0) bn_acc_add(a.bacc, COUT, tile_id, 0, n0 + wave * 16 + (lane & 15), st1[0]);
+      if (tg == tq) bn_acc_add(a.bacc, COUT, tile_id, 1, n0 + wave * 16 + (lane & 15), d2);
+    } else {
+      float* sp = a.stat_part + (size_t)(n0 + wave * 16 + (lane & 15)) * a.ntiles + tile_id;
+      if (tg == 0) sp[0] = st1[0];
+      if (tg == tq) sp[(size_t)COUT * a.ntiles] = d2;
+    }
   }
   epi.end(a, red, n0, tile_id);
   EAE_STAMP(7);

@@ -197,7 +197,9 @@ int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, co
 // ---------------------------------------------------------------------------------------------------------------
 __global__ EAE_NO_PK __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n4, float b1, float b2, float step_size,
-                                                    float bc2_sqrt, float eps, float wd, float gscale) {
+                                                    float bc2_sqrt, float eps, float wd, float gscale, uint4* __restrict__ zbuf, long zn16) {
+  // side job: clear the BatchNorm statistics accumulators for the next step (every consumer of this step has finished)
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zn16; i += (long)gridDim.x * 256) zbuf[i] = make_uint4(0, 0, 0, 0);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
     float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -268,14 +270,14 @@ int eae_launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v
 }
 
 int eae_launch_adam_scaled(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
-                           double eps, double wd, long long step, float gscale) {
+                           double eps, double wd, long long step, float gscale, void* zero_buf, long long zero_bytes) {
   if (n % 4) return eae_set_error(-2, "adam: arena length must be a multiple of 4");
   double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
   long n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4, (float)b1, (float)b2, (float)(lr / bc1),
-                     (float)sqrt(bc2), (float)eps, (float)wd, gscale);
+                     (float)sqrt(bc2), (float)eps, (float)wd, gscale, (uint4*)zero_buf, (long)(zero_bytes / 16));
   EAE_LAUNCH_CHECK();
   return 0;
 }
