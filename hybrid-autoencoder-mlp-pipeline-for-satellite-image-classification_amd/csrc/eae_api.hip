@@ -194,7 +194,8 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
                        eae_conv_s2_ntiles(1, Bi, c->H / 8, c->W / 8), eae_conv_s2_ntiles(1, Bi, c->H / 4, c->W / 4)};
     for (int l = 0; l < 7; ++l) {
       int cp = 8;
-      while (cp < 64 && cp * 2 * 16 <= nt[l]) cp *= 2;        // about one accumulator set per 16 producer workgroups
+      while (cp < 64 && cp * 2 * 16 <= nt[l]) cp *= 2;        // about one accumulator set per 16 producer workgroups ...
+      while (cp > BN_FOLD_K * (256 / BN_C[l])) cp /= 2;       // ... but at most BN_FOLD_K sets per consumer thread
       c->acc_copies[l] = cp;
       o_acc[l] = acc_total;
       acc_total += (size_t)cp * 2 * BN_C[l] * 8;

@@ -170,17 +170,32 @@ __device__ __forceinline__ void bn_acc_add(const BnAcc& b, int C, int tile_id, i
   unsigned long long* p = b.acc + ((size_t)(tile_id & (b.copies - 1)) * 2 + which) * C + ch;
   __hip_atomic_fetch_add(p, (unsigned long long)(long long)llrintf(v * b.scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// All 256 threads of the workgroup.  table = LDS float [4][C]; red = LDS long long [2][256] (may alias any idle buffer).
+// Split in two so that the accumulator loads can be ISSUED before the kernel's own first loads (vector-memory results return in
+// issue order: a prologue whose loads queue behind the patch loads would wait for all of them) and CONSUMED after those are in
+// flight.  copies <= 4 * (256 / C)  (at most 4 accumulator sets per thread).
+constexpr int BN_FOLD_K = 4;
+struct BnFoldRegs { long long v[2][BN_FOLD_K]; };
 template <int C>
-__device__ __forceinline__ void bn_fold_fwd(const BnFold& f, float* table, long long* red, bool writer) {
+__device__ __forceinline__ void bn_fold_load(const BnFold& f, BnFoldRegs& r) {
   static_assert(C <= 256 && 256 % C == 0, "channel count");
   constexpr int G = 256 / C;
   const int tid = threadIdx.x, ch = tid % C, grp = tid / C;
-  long long s1 = 0, s2 = 0;
-  for (int k = grp; k < f.copies; k += G) {
-    s1 += (long long)f.acc[((size_t)k * 2 + 0) * C + ch];
-    s2 += (long long)f.acc[((size_t)k * 2 + 1) * C + ch];
+#pragma unroll
+  for (int j = 0; j < BN_FOLD_K; ++j) {
+    const int k = grp + j * G;
+    const bool ok = k < f.copies;
+    r.v[0][j] = ok ? (long long)f.acc[((size_t)k * 2 + 0) * C + ch] : 0;
+    r.v[1][j] = ok ? (long long)f.acc[((size_t)k * 2 + 1) * C + ch] : 0;
   }
+}
+// All 256 threads of the workgroup.  table = LDS float [4][C]; red = LDS long long [2][256] (may alias any idle buffer).
+template <int C>
+__device__ __forceinline__ void bn_fold_fwd_finish(const BnFold& f, const BnFoldRegs& r, float* table, long long* red, bool writer) {
+  constexpr int G = 256 / C;
+  const int tid = threadIdx.x, ch = tid % C, grp = tid / C;
+  long long s1 = 0, s2 = 0;
+#pragma unroll
+  for (int j = 0; j < BN_FOLD_K; ++j) { s1 += r.v[0][j]; s2 += r.v[1][j]; }
   red[tid] = s1; red[256 + tid] = s2;
   __syncthreads();
   if (grp == 0) {
@@ -204,6 +219,12 @@ __device__ __forceinline__ void bn_fold_fwd(const BnFold& f, float* table, long 
     }
   }
   __syncthreads();
+}
+template <int C>
+__device__ __forceinline__ void bn_fold_fwd(const BnFold& f, float* table, long long* red, bool writer) {
+  BnFoldRegs r;
+  bn_fold_load<C>(f, r);
+  bn_fold_fwd_finish<C>(f, r, table, red, writer);
 }
 
 #define EAE_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return eae_set_error(-3, hipGetErrorString(e__)); } while (0)

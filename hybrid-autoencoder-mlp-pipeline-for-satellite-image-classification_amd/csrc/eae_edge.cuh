@@ -279,6 +279,9 @@ __global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
   const int iy0 = tyb * E_TH, ix0 = txb * E_TW;
   const int kgs = tid & 3, kgl = lane >> 4;
   ChanCoef<SRC> cc;
+  BnFoldRegs fr;
+  const bool folded = SRC == SRC_BNRELU && a.fold.acc != nullptr;
+  if (folded) bn_fold_load<32>(a.fold, fr);       // before the patch loads: results return in issue order
   RawPiece<SRC> raw[NPA];
   bool val[NPA];
 #pragma unroll
@@ -294,8 +297,8 @@ __global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
   {   // coefficient table of the 32-channel source layer (folded BatchNorm finalize) while the loads are in flight
     __shared__ float coef_tab[4 * 32];
     const float* coefp = a.src.coef;
-    if (SRC == SRC_BNRELU && a.fold.acc != nullptr) {
-      bn_fold_fwd<32>(a.fold, coef_tab, reinterpret_cast<long long*>(sl), blockIdx.x == 0);
+    if (folded) {
+      bn_fold_fwd_finish<32>(a.fold, fr, coef_tab, reinterpret_cast<long long*>(sl), blockIdx.x == 0);
       coefp = coef_tab;
     }
     cc.load(coefp, 32, kgs * 8);

@@ -304,10 +304,14 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT)) void igemm_s2_kernel(
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) wf[tap] = *reinterpret_cast<const bf16x8*>(wrow + tap * CIN + chunk * 32);
   };
+  // accumulator loads first, then the first chunk's weight / patch loads: the table is built while those are in flight
+  BnFoldRegs fr;
+  const bool folded = SRC == SRC_BNRELU && a.fold.acc != nullptr;
+  if (folded) bn_fold_load<CIN>(a.fold, fr);
   load_w(0);
-  issue(0, false);          // the first chunk's loads fly while the coefficient table is being built
-  if (SRC == SRC_BNRELU && a.fold.acc != nullptr) {
-    bn_fold_fwd<CIN>(a.fold, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0);
+  issue(0, false);
+  if (folded) {
+    bn_fold_fwd_finish<CIN>(a.fold, fr, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0);
     coefp = coef_tab;
   }
   cc.load(coefp, CIN, kgs * 8);
