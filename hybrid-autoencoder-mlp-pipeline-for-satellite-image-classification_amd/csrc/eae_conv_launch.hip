@@ -29,17 +29,9 @@ int launch(const ConvArgs& a, hipStream_t st) {   // NOLINT
 template <int CIN, int COUT, int BN, int SRC, int EPI>
 int conv_geo(const ConvArgs& a, hipStream_t st) {
   const int Hp = a.Hin / 2, Wp = a.Win / 2;
-#ifdef EAE_P64
-  if (Wp % 16 == 0 && Hp % 4 == 0) return launch<KIND_CONV, CIN, COUT, BN, 16, 4, 1, SRC, EPI>(a, st);
-#endif
   if (Wp % 16 == 0 && Hp % 8 == 0) return launch<KIND_CONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st);
-#ifdef EAE_SMALLP64
-  if (Wp == 8 && Hp == 8) return launch<KIND_CONV, CIN, COUT, BN, 8, 8, 1, SRC, EPI>(a, st);
-  if (Wp == 4 && Hp == 4) return launch<KIND_CONV, CIN, COUT, BN, 4, 4, 4, SRC, EPI>(a, st);
-#else
   if (Wp == 8 && Hp == 8) return launch<KIND_CONV, CIN, COUT, BN, 8, 8, 2, SRC, EPI>(a, st);
   if (Wp == 4 && Hp == 4) return launch<KIND_CONV, CIN, COUT, BN, 4, 4, 8, SRC, EPI>(a, st);
-#endif
   return eae_set_error(-2, "conv_s2: unsupported spatial size (output must be 4x4, 8x8 or a multiple of 8x16)");
 }
 
@@ -92,17 +84,9 @@ int eae_launch_deconv_s2(const ConvArgs& a, int cin, int cout, int src, int epi,
 int eae_conv_s2_ntiles(int kind, int B, int Hin, int Win) {
   if (kind == 0) {
     int Hp = Hin / 2, Wp = Win / 2;
-#ifdef EAE_P64
-    if (Wp % 16 == 0 && Hp % 4 == 0) return B * (Hp / 4) * (Wp / 16);
-#endif
     if (Wp % 16 == 0 && Hp % 8 == 0) return B * (Hp / 8) * (Wp / 16);
-#ifdef EAE_SMALLP64
-    if (Wp == 8 && Hp == 8) return B;
-    if (Wp == 4 && Hp == 4) return (B + 3) / 4;
-#else
     if (Wp == 8 && Hp == 8) return (B + 1) / 2;
     if (Wp == 4 && Hp == 4) return (B + 7) / 8;
-#endif
     return -1;
   }
   if (Win % 16 == 0 && Hin % 8 == 0) return B * (Hin / 8) * (Win / 16);

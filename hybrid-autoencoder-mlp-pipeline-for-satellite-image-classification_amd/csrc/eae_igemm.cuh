@@ -53,9 +53,6 @@ struct ConvArgs {
 #define EAE_STAMP_WG(k) do {} while (0)
 #endif
 
-#ifndef EAE_LDS_SLACK
-#define EAE_LDS_SLACK 0
-#endif
 enum { KIND_CONV = 0, KIND_DECONV = 1 };
 constexpr int PIX_STRIDE = 40;       // edge / wgrad kernels: bf16 elements per staged pixel, 32 channels + 8 pad (80 B)
 // igemm patch: 2-D image [img][row][PWS pixels][32 ch], 64 B per pixel and no padding bytes (a 16x8 conv tile then fits
@@ -396,11 +393,7 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT)) void igemm_s2_kernel(
   constexpr int PHG = (KIND == KIND_CONV) ? 1 : 2, R2 = P * PHG;
   bf16_t* tile = smem;
   float* red = reinterpret_cast<float*>(smem + R2 * TS);
-#ifdef EAE_NO_MFMA_STATS
-  TileEpilogue<COUT, BN, EPI, true> epi;
-#else
   TileEpilogue<COUT, BN, EPI, false> epi;
-#endif
   epi.begin(a, n0);
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (EPI == EPI_FWD) bv = *reinterpret_cast<const float4*>(a.bias + n0 + wn * 16 + kgl * 4);
@@ -409,11 +402,7 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT)) void igemm_s2_kernel(
   //   sum_p Y[p][j]   = (ones^T . Y)[.][j]         (any row of an MFMA with an all-ones A operand)
   //   sum_p Y[p][j]^2 = diag(Y^T . Y)[j]           (A and B are the same transposed-read fragment)
   // wave w < BN/16 owns the 16 channels of n-tile w and sweeps all P rows of every phase.
-#ifdef EAE_NO_MFMA_STATS
-  const bool do_stats = false;
-#else
   const bool do_stats = (EPI == EPI_FWD) && (a.stat_part != nullptr || a.bacc.acc != nullptr) && wave < BN / 16;
-#endif
   f32x4 st1 = (f32x4){0.f, 0.f, 0.f, 0.f}, st2 = (f32x4){0.f, 0.f, 0.f, 0.f};
   bf16x8 ones;
 #pragma unroll
@@ -480,5 +469,5 @@ constexpr size_t igemm_smem() {
   using G = Geo<KIND, TW, TH, NI>;
   constexpr size_t patch = (size_t)NI * G::PH * G::RS * 2;
   constexpr size_t tile = (size_t)G::P * (KIND == KIND_CONV ? 1 : 2) * (BN + 8) * 2 + (size_t)2 * (256 / (BN / 8)) * BN * 4;
-  return (patch > tile ? patch : tile) + EAE_LDS_SLACK;
+  return patch > tile ? patch : tile;
 }
