@@ -207,6 +207,7 @@ def main():
                 out["cpu_baseline"] = {"error": str(e)[:200]}
         print(json.dumps(out), flush=True)
     if dist_on:
+        dist.barrier(device_ids=[local_rank])      # every rank leaves together (rank 0 ran its local roofline pass meanwhile)
         dist.destroy_process_group()
 
 
