@@ -438,6 +438,15 @@ void fold_consumer(eae_ctx* c, BnFold& f, int l, long long count, bool train) {
   f.coef_out = c->coef_f[l];
 }
 
+// the statistics accumulators of a train-mode forward must be zero when its producers start: the engine's own Adam clears them
+// as a side job, any other sequence (forward only, external optimizer, encoder / decoder alone) pays one memset here
+int prep_accumulators(eae_ctx* c, hipStream_t st, bool train) {
+  if (!train || !c->fold_fwd) return 0;
+  if (!c->acc_clean) EAE_HIP(hipMemsetAsync(c->acc_base, 0, c->acc_bytes, st));
+  c->acc_clean = false;
+  return 0;
+}
+
 int bn_fwd_finalize(eae_ctx* c, hipStream_t st, int l, int ntiles, long long count, bool train) {
   if (train && c->fold_fwd) return 0;       // folded into the producer (accumulators) and the next kernel (prologue)
   const float* gamma = c->P + c->poff[BN_GAMMA_IDX[l]];
@@ -560,10 +569,7 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
   const bool train = io->train != 0;
   c->fwd_ready = train; c->fwd_B = B; c->fwd_head = io->head; c->fwd_x = io->x;
   RC(ensure_packed(c, st));
-  if (train && c->fold_fwd) {
-    if (!c->acc_clean) EAE_HIP(hipMemsetAsync(c->acc_base, 0, c->acc_bytes, st));
-    c->acc_clean = false;
-  }
+  RC(prep_accumulators(c, st, train));
   RC(run_encoder(c, st, io->x, B, train));
   const double numel = (double)B * 3.0 * c->H * c->W;
   const float gscale = (float)(2.0 * io->alpha / numel);
@@ -870,6 +876,7 @@ extern "C" int eae_encoder_forward(eae_ctx* c, void* stream, const float* x, int
   hipStream_t st = (hipStream_t)stream;
   c->fwd_ready = false;
   RC(ensure_packed(c, st));
+  RC(prep_accumulators(c, st, train != 0));
   RC(run_encoder(c, st, x, B, train != 0));
   EAE_HIP(hipMemcpyAsync(z, c->z, (size_t)B * c->L * 4, hipMemcpyDeviceToDevice, st));
   return 0;
@@ -882,6 +889,7 @@ extern "C" int eae_decoder_forward(eae_ctx* c, void* stream, const float* z, int
   hipStream_t st = (hipStream_t)stream;
   c->fwd_ready = false;
   RC(ensure_packed(c, st));
+  RC(prep_accumulators(c, st, train != 0));
   return run_decoder(c, st, z, B, train != 0, nullptr, 0.f, x_hat, false, false);
 }
 

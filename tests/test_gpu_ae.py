@@ -392,3 +392,26 @@ def test_full_size_batch512_properties():
         grads[alpha] = g
     d35, d30 = grads[35.0] - grads[20.0], grads[30.0] - grads[20.0]
     assert G.cosine(d35, 1.5 * d30) > 0.999 and G.relmax(d35, 1.5 * d30) < 3e-2, (G.cosine(d35, 1.5 * d30), G.relmax(d35, 1.5 * d30))
+
+
+def test_encoder_decoder_alone_in_train_mode_repeatable():
+    """Encoder.forward / Decoder.forward on their own in TRAIN mode (batch statistics): the folded BatchNorm accumulators must
+    be clean for every call, whatever ran before -- the same call twice (running stats restored in between) gives the same
+    bits, and it agrees with the full forward's z / x_hat."""
+    x, y = gu.make_images(8, 55)
+    xd, yd = _cuda(x), _cuda(y)
+    m = _model()
+    m.train()
+    eng = _engine(m)
+    bn0 = eng.bn_running.clone(); nbt0 = eng.bn_nbt.clone()
+    xh_f, lg_f, z_f = eng.forward(xd, labels=yd, train=True, alpha=35.0)
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(2):
+        eng.bn_running.copy_(bn0); eng.bn_nbt.copy_(nbt0)
+        z = eng.encoder(xd, train=True)
+        xh = eng.decoder(z, train=True)
+        torch.cuda.synchronize()
+        outs.append((z.clone(), xh.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], z_f) and torch.equal(outs[0][1], xh_f)
