@@ -442,7 +442,7 @@ void fold_consumer(eae_ctx* c, BnFold& f, int l, long long count, bool train) {
 // as a side job, any other sequence (forward only, external optimizer, encoder / decoder alone) pays one memset here
 int prep_accumulators(eae_ctx* c, hipStream_t st, bool train) {
   if (!train || !c->fold_fwd) return 0;
-  if (!c->acc_clean) EAE_HIP(hipMemsetAsync(c->acc_base, 0, c->acc_bytes, st));
+  if (!c->acc_clean || c->capturing) EAE_HIP(hipMemsetAsync(c->acc_base, 0, c->acc_bytes, st));   // a captured step always carries it
   c->acc_clean = false;
   return 0;
 }
@@ -847,14 +847,16 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
   RC(eae_launch_set_dyn(st, c->dyn, lr, 0.9, 0.999, 0.0, c->adam_step));
   if (ent && ent->exec) {
     EAE_HIP(hipGraphLaunch(ent->exec, st));
-    c->fwd_ready = false; c->packed = false;
+    c->fwd_ready = false; c->packed = false; c->acc_clean = false;
     return 0;
   }
   const bool capture = ent && ent->seen >= 3;      // two eager warm-up steps with this key first (lazy kernel attributes etc.)
   if (capture) EAE_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+  c->capturing = capture;
   int rc = forward_impl(c, st, io, true);
   if (!rc) rc = backward_impl(c, st, io);
   if (!rc) rc = eae_launch_adam_dyn(st, c->P, c->G, c->M, c->V, c->poff[38], 0.9, 0.999, 1e-8, c->dyn);
+  c->capturing = false;
   c->packed = false;
   if (capture) {
     hipGraph_t g = nullptr;
