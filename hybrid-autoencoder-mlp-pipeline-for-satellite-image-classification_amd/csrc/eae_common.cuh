@@ -153,6 +153,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* row_ptr_lo, const bf16_t
 //             over 256 threads) and builds the coefficient table in LDS; workgroup 0 also stores the table for the kernels
 //             that need it later and updates the running statistics.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr long long BN_ACC_POISON = 1LL << 61;
 struct BnAcc {
   unsigned long long* acc;   // [copies][2][C]; zero before the producer runs; nullptr: per-tile partials + finalize kernel
   int copies;                // power of two
@@ -168,7 +169,11 @@ struct BnFold {
 };
 __device__ __forceinline__ void bn_acc_add(const BnAcc& b, int C, int tile_id, int which, int ch, float v) {
   unsigned long long* p = b.acc + ((size_t)(tile_id & (b.copies - 1)) * 2 + which) * C + ch;
-  __hip_atomic_fetch_add(p, (unsigned long long)(long long)llrintf(v * b.scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // a non-finite partial (diverged run) must poison the statistics like it does in floating point: it is added as 2^61, which
+  // no finite data can reach, and the consumer turns such a sum back into NaN
+  const float sv = v * b.scale;
+  const long long q = (fabsf(sv) < 9.0e18f) ? llrintf(sv) : BN_ACC_POISON;
+  __hip_atomic_fetch_add(p, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Split in two so that the accumulator loads can be ISSUED before the kernel's own first loads (vector-memory results return in
 // issue order: a prologue whose loads queue behind the patch loads would wait for all of them) and CONSUMED after those are in
@@ -201,7 +206,8 @@ __device__ __forceinline__ void bn_fold_fwd_finish(const BnFold& f, const BnFold
   if (grp == 0) {
 #pragma unroll
     for (int g = 1; g < G; ++g) { s1 += red[g * C + ch]; s2 += red[256 + g * C + ch]; }
-    const double a = (double)s1 * (double)f.inv_scale, b = (double)s2 * (double)f.inv_scale;
+    const bool poisoned = s1 >= (BN_ACC_POISON >> 1) || s1 <= -(BN_ACC_POISON >> 1) || s2 >= (BN_ACC_POISON >> 1) || s2 <= -(BN_ACC_POISON >> 1);
+    const double a = poisoned ? (double)__builtin_nanf("") : (double)s1 * (double)f.inv_scale, b = (double)s2 * (double)f.inv_scale;
     const double mean = a / f.count;
     double var = b / f.count - mean * mean;
     if (var < 0.0) var = 0.0;

@@ -415,3 +415,32 @@ def test_encoder_decoder_alone_in_train_mode_repeatable():
         outs.append((z.clone(), xh.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[0][0], z_f) and torch.equal(outs[0][1], xh_f)
+
+
+def test_non_finite_input_poisons_the_step_like_the_reference():
+    """A diverged run must look diverged (the reference's grid contains learning rates that blow up, R.md:2447-2450): a
+    non-finite activation has to reach the loss through the fixed-point BatchNorm statistics as NaN, not as a finite number."""
+    x, y = gu.make_images(8, 11)
+    x = x.copy()
+    x[3, 1, 10, 10] = np.inf
+    m = _model()
+    eng = _engine(m)
+    xh, lg, z = eng.forward(_cuda(x), labels=_cuda(y), train=True, alpha=35.0)
+    torch.cuda.synchronize()
+    assert not np.isfinite(eng.loss_last.cpu().numpy()[0])
+    # (z itself may come out finite: the packed-bf16 ReLU is an integer max, which sends negative-signed NaNs to 0 where
+    #  torch.relu keeps them -- DESIGN.md section 5, deviations; a diverged PARAMETER always reaches the loss)
+    # and the next, finite batch is unaffected by what the poisoned one left in the accumulators
+    x2, y2 = gu.make_images(8, 100)
+    m2 = _model()
+    e2 = _engine(m2)
+    ref = [t.clone() for t in e2.forward(_cuda(x2), labels=_cuda(y2), train=True, alpha=35.0)]
+    eng.bn_running.copy_(e2.bn_running); eng.bn_nbt.copy_(e2.bn_nbt)
+    m3 = _model()
+    e3 = _engine(m3)
+    e3.forward(_cuda(x), labels=_cuda(y), train=True, alpha=35.0)
+    load_state_np(m3, ae_state_np())
+    e3.params_changed()
+    got = e3.forward(_cuda(x2), labels=_cuda(y2), train=True, alpha=35.0)
+    torch.cuda.synchronize()
+    assert torch.equal(got[2], ref[2]) and torch.equal(got[0], ref[0])
