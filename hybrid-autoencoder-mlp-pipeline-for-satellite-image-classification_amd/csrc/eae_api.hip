@@ -196,6 +196,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
       int cp = 8;
       while (cp < 64 && cp * 2 * 16 <= nt[l]) cp *= 2;        // about one accumulator set per 16 producer workgroups ...
       while (cp > BN_FOLD_K * (256 / BN_C[l])) cp /= 2;       // ... but at most BN_FOLD_K sets per consumer thread
+      if (const char* e = getenv("EAE_ACC_COPIES_MAX")) { int mx = atoi(e); while (mx >= 1 && cp > mx) cp /= 2; }
       c->acc_copies[l] = cp;
       o_acc[l] = acc_total;
       acc_total += (size_t)cp * 2 * BN_C[l] * 8;
