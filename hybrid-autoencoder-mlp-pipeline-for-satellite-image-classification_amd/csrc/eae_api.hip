@@ -217,14 +217,14 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
     PackDesc d; d.src_off = src; d.dst_off = (long long)dst; d.count = cnt; d.mode = mode; d.d0 = d0; d.d1 = d1; d.d2 = d2; d.out_f32 = f32;
     descs.push_back(d);
   };
-  c->pk_c1 = pcarve(32 * 32 * 2); add(c->poff[0], c->pk_c1, 32 * 32, PACK_K27, 32, 3, 0, 0);
+  c->pk_c1 = pcarve(32 * 64 * 2); add(c->poff[0], c->pk_c1, 32 * 64, PACK_K36, 32, 3, 0, 0);
   for (int i = 0; i < 6; ++i) {
     long long n = (long long)W3_A[i] * W3_B[i] * 9;
     c->pk_p1[i] = pcarve(n * 2); add(c->poff[W3_PARAM[i]], c->pk_p1[i], n, PACK_3x3_P1, W3_A[i], W3_B[i], 0, 0);
     c->pk_p2[i] = pcarve(n * 2); add(c->poff[W3_PARAM[i]], c->pk_p2[i], n, PACK_3x3_P2, W3_A[i], W3_B[i], 0, 0);
   }
   c->pk_d4j = pcarve(16 * 128 * 2); add(c->poff[32], c->pk_d4j, 16 * 128, PACK_DECONV4_JOINT, 0, 0, 0, 0);
-  c->pk_d4k = pcarve(32 * 32 * 2); add(c->poff[32], c->pk_d4k, 32 * 32, PACK_K27, 32, 3, 0, 0);
+  c->pk_d4k = pcarve(32 * 64 * 2); add(c->poff[32], c->pk_d4k, 32 * 64, PACK_K36, 32, 3, 0, 0);
   const long long LK = c->L * c->K;
   c->pk_we1 = pcarve(LK * 2); add(c->poff[16], c->pk_we1, LK, PACK_FC_ROWMAJOR_KPERM, c->L, 256, (int)c->Pn, 0);
   c->pk_we2 = pcarve(LK * 2); add(c->poff[16], c->pk_we2, LK, PACK_FC_TRANS_KPERM, c->L, 256, (int)c->Pn, 0);

@@ -91,13 +91,17 @@ __device__ __forceinline__ void build_im2col27(const bf16_t* p3, bf16_t* at) {
 struct EdgeArgs {
   const void* src3;        // fp32 NCHW [B,3,H,W] or bf16 NHWC4 [B,H,W,4]
   int B, H, W;             // spatial size of the 3-channel tensor
-  ConvArgs c;              // wpack [32][32], bias, out [B,H/2,W/2,32], stat_part, yprev, prev_coef
+  ConvArgs c;              // wpack [32][64] (k = tap*4 + c, zero where c == 3 or k >= 36), bias, out [B,H/2,W/2,32], stat_part, yprev, prev_coef
 };
 
+// No im2col tile: with k = tap*4 + c (c = 0..3, the 4th channel and k >= 36 are zero in the weights: K = 64, two MFMA k-steps)
+// a lane's 8 consecutive k are TWO whole pixels of the staged [row][col][4] patch, so the pixel operand is two ds_read_b64
+// straight from the patch.  The weights are the MFMA A operand: an accumulator lane holds 4 consecutive output channels of
+// one pixel (8-byte tile writes instead of 16 two-byte ones).
 template <int SRC3, int EPI>
 __global__ __launch_bounds__(256) void edge_conv_kernel(EdgeArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t p3[E_PATCH];
-  __shared__ __attribute__((aligned(16))) bf16_t at[E_AT];            // im2col tile, later the output tile [128][40]
+  __shared__ __attribute__((aligned(16))) bf16_t at[E_AT];            // output tile [128][40]
   __shared__ __attribute__((aligned(16))) float red[2 * 64 * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Hout = a.H >> 1, Wout = a.W >> 1;
@@ -106,41 +110,48 @@ __global__ __launch_bounds__(256) void edge_conv_kernel(EdgeArgs a) {
   const int txb = t % tiles_x; t /= tiles_x;
   const int tyb = t % tiles_y; t /= tiles_y;
   const int n = t;
-#ifndef EAE_DIAG
-#define EAE_DIAG 0
-#endif
-  if (!(EAE_DIAG & 1)) stage_patch3<SRC3>(a.src3, p3, n, a.H, a.W, 2 * tyb * E_TH - 1, 2 * txb * E_TW - 1);
-  if (!(EAE_DIAG & 2)) build_im2col27(p3, at);
-  __syncthreads();
   const int kgl = lane >> 4;
+  // weight fragments first (independent of the patch): A[channel][k], 2 m-tiles x 2 k-steps
+  bf16x8 wf[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      wf[mt][ks] = *reinterpret_cast<const bf16x8*>(a.c.wpack + (mt * 16 + (lane & 15)) * 64 + ks * 32 + kgl * 8);
+  stage_patch3<SRC3>(a.src3, p3, n, a.H, a.W, 2 * tyb * E_TH - 1, 2 * txb * E_TW - 1);      // ends with a barrier
   f32x4 acc[2][2];
-  bf16x8 af[2], bfr[2];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-    af[mi] = *reinterpret_cast<const bf16x8*>(at + ((wave * 2 + mi) * 16 + (lane & 15)) * PIX_STRIDE + kgl * 8);
+  for (int nt = 0; nt < 2; ++nt) {
+    const int m = (wave * 2 + nt) * 16 + (lane & 15);                // this lane's pixel of the n-tile
+    const int ty = m / E_TW, tx = m % E_TW;
+    const bf16_t* pb = p3 + ((2 * ty) * E_PW + 2 * tx) * 4;
+    // k-step 0: taps 2*kgl and 2*kgl+1; k-step 1: tap 8 (lane group 0 only), everything else multiplies zero weights
+    const int t0 = 2 * kgl, t1 = 2 * kgl + 1;
+    union { bf16x8 v; uint2 h[2]; } f0, f1;
+    f0.h[0] = *reinterpret_cast<const uint2*>(pb + ((t0 / 3) * E_PW + (t0 % 3)) * 4);
+    f0.h[1] = *reinterpret_cast<const uint2*>(pb + ((t1 / 3) * E_PW + (t1 % 3)) * 4);
+    f1.h[0] = (kgl == 0) ? *reinterpret_cast<const uint2*>(pb + (2 * E_PW + 2) * 4) : make_uint2(0, 0);
+    f1.h[1] = make_uint2(0, 0);
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-    bfr[ni] = *reinterpret_cast<const bf16x8*>(a.c.wpack + (ni * 16 + (lane & 15)) * 32 + kgl * 8);
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      if (EAE_DIAG & 4) acc[mi][ni] = (f32x4){af[mi][0], bfr[ni][1], 0.f, 1.f};
-      else acc[mi][ni] = mfma16(af[mi], bfr[ni], (f32x4){0.f, 0.f, 0.f, 0.f});
+    for (int mt = 0; mt < 2; ++mt) {
+      acc[mt][nt] = mfma16(wf[mt][0], f0.v, (f32x4){0.f, 0.f, 0.f, 0.f});
+      acc[mt][nt] = mfma16(wf[mt][1], f1.v, acc[mt][nt]);
     }
-  __syncthreads();
-  if (EAE_DIAG & 8) { if (acc[0][0][0] == 1234.5f) a.c.out[0] = 1; return; }
+  }
+  // D[channel][pixel]: col = lane & 15 = pixel, rows (lane >> 4) * 4 + r = 4 consecutive channels
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    int col = ni * 16 + (lane & 15);
-    float bv = (EPI == EPI_FWD) ? a.c.bias[col] : 0.f;
+  for (int mt = 0; mt < 2; ++mt) {
+    const int ch = mt * 16 + (lane >> 4) * 4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == EPI_FWD) bv = *reinterpret_cast<const float4*>(a.c.bias + ch);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = (wave * 2 + mi) * 16 + (lane >> 4) * 4 + r;
-        at[row * 40 + col] = (bf16_t)f2bf(acc[mi][ni][r] + bv);
-      }
+    for (int nt = 0; nt < 2; ++nt) {
+      const int m = (wave * 2 + nt) * 16 + (lane & 15);
+      uint2 w2;
+      w2.x = pk2((f32x2){acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y});
+      w2.y = pk2((f32x2){acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w});
+      *reinterpret_cast<uint2*>(at + m * 40 + ch) = w2;
+    }
   }
   __syncthreads();
   auto rowmap = [=](int row) -> long {

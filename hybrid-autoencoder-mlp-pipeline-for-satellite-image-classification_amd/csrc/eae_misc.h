@@ -3,7 +3,7 @@
 #include <stdint.h>
 
 enum { PACK_COPY = 0, PACK_3x3_P1, PACK_3x3_P2, PACK_K27, PACK_DECONV4_JOINT, PACK_FC_ROWMAJOR_KPERM, PACK_FC_TRANS_KPERM,
-       PACK_FC_ROWPERM, PACK_FC_ROWPERM_TRANS };
+       PACK_FC_ROWPERM, PACK_FC_ROWPERM_TRANS, PACK_K36 };
 
 struct PackDesc {
   long long src_off;   // element offset into the fp32 parameter arena

@@ -139,6 +139,11 @@ __device__ __forceinline__ float pack_fetch(const PackDesc& d, const float* __re
       int tap = k / 3, c = k % 3;
       return src[((long)a * 3 + c) * 9 + tap];
     }
+    case PACK_K36: {      // dst [A][64] with k = tap*4 + c (zero for c == 3 and k >= 36)  <- src [A][3][3][3]   (edge_conv_kernel)
+      int k = i & 63; int a = i >> 6;
+      if (k >= 36 || (k & 3) == 3) return 0.f;
+      return src[((long)a * 3 + (k & 3)) * 9 + (k >> 2)];
+    }
     case PACK_DECONV4_JOINT: {   // dst [16][128]: n = phase*3+co, k = nb*32+ci  <- src [32 ci][3 co][3][3]
       int k = i & 127; int n = i >> 7;
       if (n >= 12) return 0.f;

@@ -133,7 +133,7 @@ int eae_op_conv_s2(void* stream, int kind, eae_src src, int cin, int cout, int B
                    const float* bias, void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef);
 int eae_op_conv_s2_ntiles(int kind, int B, int Hin, int Win);
 /* first / last layer kernels: src3_kind 0 = fp32 NCHW [B,3,H,W], 1 = bf16 NHWC4 [B,H,W,4]; out [B,H/2,W/2,32] */
-int eae_op_edge_conv(void* stream, int src3_kind, const void* src3, int B, int H, int W, const void* wpack32x32,
+int eae_op_edge_conv(void* stream, int src3_kind, const void* src3, int B, int H, int W, const void* wpack32x64 /* k = tap*4 + c */,
                      const float* bias, void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef);
 int eae_op_edge_wgrad(void* stream, int src3_kind, const void* src3, int B, int H, int W, eae_src side, float* scratch,
                       long long scratch_floats, float* dw /*[32][3][3][3]*/);

@@ -113,8 +113,10 @@ def test_edge_conv_and_wgrad(lib):
     w = (rng.standard_normal((32, 3, 3, 3)) * 0.2).astype(np.float32)
     b = rng.standard_normal(32).astype(np.float32)
     wq = O.bf16_round(w)
-    wp = np.zeros((32, 32), np.float32)
-    wp[:, :27] = wq.reshape(32, 3, 9).transpose(0, 2, 1).reshape(32, 27)       # k = tap*3 + c
+    wp = np.zeros((32, 64), np.float32)
+    wp4 = np.zeros((32, 9, 4), np.float32)
+    wp4[:, :, :3] = wq.reshape(32, 3, 9).transpose(0, 2, 1)                    # k = tap*4 + c (4th channel and k >= 36: zero)
+    wp[:, :36] = wp4.reshape(32, 36)
     wpd = G.f32(wp).to(torch.bfloat16)
     xd, bd = G.f32(x), G.f32(b)
     out = torch.empty((B, 32, 32, 32), dtype=torch.bfloat16, device=G.dev())

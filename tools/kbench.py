@@ -69,7 +69,7 @@ for (cin, cout, h) in ((32, 64, 32), (64, 128, 16), (128, 256, 8)):
     flops = 2.0 * B * (h // 2) ** 2 * 9 * cin * cout
     rows.append((f"wgrad {cout}x{cin} Hs{h // 2} (+reduce)", t, flops / t / 1e6, (small.numel() * 2 + big.numel()) * 2 / t / 1e3))
 
-x = torch.rand((B, 3, 64, 64), device=dev); wp = bf((32, 32)); bias = torch.randn(32, device=dev)
+x = torch.rand((B, 3, 64, 64), device=dev); wp = bf((32, 64)); bias = torch.randn(32, device=dev)
 out = bf((B, 32, 32, 32)); part = torch.zeros((B * 8, 2, 32), device=dev)
 t = timeit(lambda: check(lib.eae_op_edge_conv(G.stream(), 0, G.ptr(x), B, 64, 64, G.ptr(wp), G.ptr(bias), G.ptr(out), G.ptr(part), 0, None, None)))
 rows.append(("edge_conv (conv1 fwd)", t, 2.0 * B * 1024 * 27 * 32 / t / 1e6, (x.numel() * 4 + out.numel() * 2) / t / 1e3))

@@ -17,7 +17,7 @@ from eae_amd._lib import check  # noqa: E402
 lib = _lib.load()
 dev = torch.device("cuda:0")
 B = 512
-x3 = torch.rand((B, 3, 64, 64), device=dev); w3 = (torch.randn((32, 32), device=dev) * 0.1).to(torch.bfloat16)
+x3 = torch.rand((B, 3, 64, 64), device=dev); w3 = (torch.randn((32, 64), device=dev) * 0.1).to(torch.bfloat16)
 out3 = torch.empty((B, 32, 32, 32), device=dev, dtype=torch.bfloat16); part3 = torch.zeros((2, 32, B * 8), device=dev); b3 = torch.randn(32, device=dev)
 main = torch.cuda.current_stream(); side = torch.cuda.Stream()
 

@@ -35,7 +35,7 @@ main = torch.cuda.current_stream(); side = torch.cuda.Stream()
 scratch = torch.empty(4 * 1024 * 1024, dtype=torch.float32, device=dev)
 dw = torch.zeros((128, 64, 3, 3), dtype=torch.float32, device=dev)
 big = (torch.randn((B, 16, 16, 64), device=dev)).to(torch.bfloat16); small = (torch.randn((B, 8, 8, 128), device=dev)).to(torch.bfloat16)
-x3 = torch.rand((B, 3, 64, 64), device=dev); w3 = (torch.randn((32, 32), device=dev) * 0.1).to(torch.bfloat16)
+x3 = torch.rand((B, 3, 64, 64), device=dev); w3 = (torch.randn((32, 64), device=dev) * 0.1).to(torch.bfloat16)
 out3 = torch.empty((B, 32, 32, 32), device=dev, dtype=torch.bfloat16); part3 = torch.zeros((2, 32, B * 8), device=dev); b3 = torch.randn(32, device=dev)
 
 
