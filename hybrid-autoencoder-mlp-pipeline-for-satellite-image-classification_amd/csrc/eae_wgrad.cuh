@@ -26,8 +26,11 @@ struct WgradArgs {
 
 constexpr int S_STRIDE = 72;   // bf16 elements per staged S row: 64 channels + 8 pad (144 B)
 
+// Register budget of two workgroups per CU (<= 256 VGPR + AGPR) although the grid only has one per CU: the kernel shares the
+// CUs with the backward-data chain of the main stream, and at 242 + 72 registers it kept those kernels' workgroups off the
+// SIMDs (step 0.585 -> 0.571 ms; a budget of three spills 300-450 bytes and costs 0.80 ms).
 template <int CS, int CB, int TW, int TH, int NI, int SMODE, int BMODE>
-__global__ __launch_bounds__(256) void wgrad_s2_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_s2_kernel(WgradArgs a) {
   static_assert(NI * TH * TW == 128, "tile must hold 128 positions");
   static_assert(CS % 64 == 0 && CB % 32 == 0, "shape");
   constexpr int PH = 2 * TH + 1, PW = 2 * TW + 1, NPIX = NI * PH * PW;
