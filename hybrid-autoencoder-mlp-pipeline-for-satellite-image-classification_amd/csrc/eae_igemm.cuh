@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT)) void igemm_s2_kernel(
   // cover whole 128-byte lines instead of every other 64 bytes (conv2 backward-data: 144 -> ~105 MB of HBM traffic per launch).
   constexpr int PHG = (KIND == KIND_CONV) ? 1 : 2, R2 = P * PHG;
   bf16_t* tile = smem;
-  float* red = reinterpret_cast<float*>(smem + R2 * TS);
+  float* red = reinterpret_cast<float*>(smem);     // aliases the tile: TileEpilogue::end() starts with a barrier after the last rows() pass
   TileEpilogue<COUT, BN, EPI, false> epi;
   epi.begin(a, n0);
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -468,6 +468,7 @@ template <int KIND, int BN, int TW, int TH, int NI>
 constexpr size_t igemm_smem() {
   using G = Geo<KIND, TW, TH, NI>;
   constexpr size_t patch = (size_t)NI * G::PH * G::RS * 2;
-  constexpr size_t tile = (size_t)G::P * (KIND == KIND_CONV ? 1 : 2) * (BN + 8) * 2 + (size_t)2 * (256 / (BN / 8)) * BN * 4;
+  constexpr size_t tile_b = (size_t)G::P * (KIND == KIND_CONV ? 1 : 2) * (BN + 8) * 2, red_b = (size_t)2 * (256 / (BN / 8)) * BN * 4;
+  constexpr size_t tile = tile_b > red_b ? tile_b : red_b;       // the reduction scratch reuses the tile region
   return patch > tile ? patch : tile;
 }
