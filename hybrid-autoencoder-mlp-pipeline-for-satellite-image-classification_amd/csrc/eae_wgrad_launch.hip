@@ -8,7 +8,10 @@ int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_fl
   WgradArgs a = a0;
   constexpr int nblk = (CS / 64) * (CB / 32);
   constexpr long long sz = (long long)CS * CB * 9;
-  int slices = 256 / nblk;
+  // 128 workgroups (half the CUs, 8 tiles each at B=512): the kernel runs beside the backward-data chain, and a grid that blankets
+  // every CU with 256-register waves leaves those kernels no SIMD to land on (128: 0.575, 256: 0.579, 64: 0.62 ms/step)
+  static const int wgs = getenv("EAE_WGRAD_WGS") ? atoi(getenv("EAE_WGRAD_WGS")) : 128;
+  int slices = wgs / nblk;
   if (slices < 1) slices = 1;
   if (slices > ntiles) slices = ntiles;
   while ((long long)slices * sz > scratch_floats && slices > 1) slices >>= 1;
