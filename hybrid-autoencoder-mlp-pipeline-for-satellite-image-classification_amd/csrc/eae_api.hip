@@ -1,10 +1,10 @@
 // C ABI of libeae.so (include/eae.h): context, arena layout, the fused forward / backward / Adam step of the
 // supervised autoencoder, and thin per-op wrappers used by the kernel-level parity tests.
 #include "eae_internal.h"
-#include "eae_igemm.cuh"
-#include "eae_edge.cuh"
-#include "eae_wgrad.cuh"
-#include "eae_fc.cuh"
+#include "eae_igemm.hip.h"
+#include "eae_edge.hip.h"
+#include "eae_wgrad.hip.h"
+#include "eae_fc.hip.h"
 #include <string>
 #include <vector>
 #include <cmath>

@@ -1,6 +1,6 @@
-// Host-side dispatch of the unified stride-2 conv / transposed-conv implicit-GEMM kernel (eae_igemm.cuh).
+// Host-side dispatch of the unified stride-2 conv / transposed-conv implicit-GEMM kernel (eae_igemm.hip.h).
 #include "eae_internal.h"
-#include "eae_igemm.cuh"
+#include "eae_igemm.hip.h"
 
 namespace {
 
@@ -8,12 +8,7 @@ template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, 
 int launch(const ConvArgs& a, hipStream_t st) {   // NOLINT
   auto kern = igemm_s2_kernel<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI>;
   constexpr size_t smem = igemm_smem<KIND, BN, TW, TH, NI>();
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return eae_set_error(-3, hipGetErrorString(e));
-    attr_done = true;
-  }
+  EAE_HIP(eae_smem_attr(reinterpret_cast<const void*>(kern), smem));
   const int Hpos = (KIND == KIND_CONV) ? a.Hin / 2 : a.Hin, Wpos = (KIND == KIND_CONV) ? a.Win / 2 : a.Win;
   const int groups = (a.B + NI - 1) / NI;
   const int ntiles = groups * (Hpos / TH) * (Wpos / TW);

@@ -4,8 +4,8 @@
 // K = 27 is padded to 32 in LDS only (one v_mfma_f32_16x16x32_bf16 K-step), N = 3 is handled by computing the four
 // sub-pixel phases jointly (N = 4 phases x 3 channels = 12 of 16 MFMA columns), never by padding in HBM.
 #pragma once
-#include "eae_common.cuh"
-#include "eae_igemm.cuh"
+#include "eae_common.hip.h"
+#include "eae_igemm.hip.h"
 
 enum { SRC3_NCHW_F32 = 0,     // fp32 planar image (the loader contract)
        SRC3_NHWC4_BF16 = 1 }; // bf16 pixels padded to 4 channels (gradient of the pre-sigmoid output)

@@ -1,7 +1,7 @@
 // Host-side dispatch of the 3-channel edge-layer kernels (enc.conv1, dec.deconv4).
 #include "eae_internal.h"
-#include "eae_edge.cuh"
-#include "eae_wgrad.cuh"
+#include "eae_edge.hip.h"
+#include "eae_wgrad.hip.h"
 
 static int check_edge_shape(int B, int H, int W) {
   if (B <= 0 || H % 8 || W % 64) return eae_set_error(-2, "edge layer: image height must be a multiple of 8 and width of 64");

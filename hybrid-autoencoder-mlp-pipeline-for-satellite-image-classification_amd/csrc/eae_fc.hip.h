@@ -6,8 +6,8 @@
 //   fc_tn_kernel : R[i][j] = sum_b T(P)[b][i] * T(Q)[b][j]      (weight gradients; reduction over the batch -> both
 //                                                                operands via the transposing LDS read)
 #pragma once
-#include "eae_common.cuh"
-#include "eae_igemm.cuh"
+#include "eae_common.hip.h"
+#include "eae_igemm.hip.h"
 
 enum { FCE_PARTIAL = 0,    // fp32 partial [kslice][M][N]       (split-K)
        FCE_BIAS_BF16 = 1,  // bf16(acc + bias[n]) -> [M][N]

@@ -1,6 +1,6 @@
 // Host-side dispatch of the latent-projection GEMMs.
 #include "eae_internal.h"
-#include "eae_fc.cuh"
+#include "eae_fc.hip.h"
 
 int eae_launch_fc_nt(hipStream_t st, const FcNtArgs& a0, int amode, int epi, int ksplit) {
   FcNtArgs a = a0;

@@ -3,7 +3,7 @@
 // One block handles HR = 8 batch rows: forward, softmax/CE, dlogits, dh, dz and the per-block partial weight gradients,
 // which are laid out exactly like the four head tensors in the parameter arena so one reduce_slices call finishes them.
 #include "eae_internal.h"
-#include "eae_common.cuh"
+#include "eae_common.hip.h"
 #include "eae_head.h"
 
 constexpr int HR = 8;   // batch rows per block

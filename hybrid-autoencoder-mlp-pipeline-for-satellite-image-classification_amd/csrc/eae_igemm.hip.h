@@ -20,7 +20,7 @@
 //   * BatchNorm reductions (forward: sum y, sum y^2; backward: sum g, sum g*xhat) are taken from the values actually
 //     stored, accumulated over all phases, and written as ONE deterministic partial per workgroup (no atomics).
 #pragma once
-#include "eae_common.cuh"
+#include "eae_common.hip.h"
 
 struct ConvArgs {
   SrcDesc src;

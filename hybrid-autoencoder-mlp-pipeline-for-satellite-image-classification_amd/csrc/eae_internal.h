@@ -13,6 +13,21 @@ int eae_conv_s2_ntiles(int kind, int B, int Hin, int Win);
 
 #define EAE_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return eae_set_error(-3, hipGetErrorString(e__)); } while (0)
 
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): the attribute belongs to the device's code object, so a
+// process-wide "done" flag would skip it for a context created later on another device.
+#include <utility>
+#include <vector>
+inline hipError_t eae_smem_attr(const void* func, size_t bytes) {
+  static thread_local std::vector<std::pair<const void*, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  for (const auto& d : done) if (d.first == func && d.second == dev) return hipSuccess;
+  e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done.emplace_back(func, dev);
+  return e;
+}
+
 #include "eae_misc.h"
 #include "eae_head.h"
 struct SrcDesc;

@@ -2,7 +2,7 @@
 // reductions -> dgamma/dbeta + apply coefficients), weight packing (fp32 master -> bf16 kernel layouts),
 // fused multi-tensor Adam, loss bookkeeping.
 #include "eae_internal.h"
-#include "eae_common.cuh"
+#include "eae_common.hip.h"
 #include "eae_misc.h"
 
 

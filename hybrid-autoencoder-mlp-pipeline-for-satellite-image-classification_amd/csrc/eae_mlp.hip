@@ -6,7 +6,7 @@
 // stay L1/L2-resident, activations live in a small global workspace, arithmetic is fp32 (matches the reference's dtype).
 // Evaluation (running statistics, rows independent) uses one block per 64 rows.
 #include "eae_internal.h"
-#include "eae_common.cuh"
+#include "eae_common.hip.h"
 #include <cmath>
 
 namespace {

@@ -1,0 +1,286 @@
+// Weight-gradient kernel of the 3x3 stride-2 conv / transposed-conv layers (aten::convolution_backward's wgrad,
+// 39 % of the reference's CPU step time; autograd of R.md:292-304, 370-378).
+//
+//   R[cs][cb][tap] = sum over positions (n,oy,ox) of  S[n,oy,ox,cs] * Bg[n,2oy-1+ky,2ox-1+kx,cb]
+//
+//   conv   layer: S = dy (gradient of the conv output, small map), Bg = input activation (big map)  -> dW[co=cs][ci=cb][ky][kx]
+//   deconv layer: S = input activation (small map), Bg = gradient of the deconv output (big map)    -> dW[ci=cs][co=cb][ky][kx]
+// i.e. both land directly in the reference's parameter layout [cs][cb][3][3].
+//
+// The reduction runs over pixels, which are the *strided* dimension of NHWC tensors, so both MFMA operands are read
+// with the hardware transposing LDS read (ds_read_b64_tr_b16): the S tile and the Bg patch sit in LDS in their natural
+// [pixel][channel] order (staged with 16-byte loads, load transforms applied once per element) and each lane supplies
+// the addresses of the gathered patch rows of its tap.
+//
+// Round-2 structure.  The round-1 kernel ran ONE 4-wave workgroup per CU through load -> wait -> stage -> barrier -> MFMA per
+// tile, so a CU had either bytes in flight or matrix work, never both (8 % of the HBM roofline in situ).  Now a workgroup is
+// 12 waves, three per SIMD, with two roles:
+//   * waves 0-3, the CONSUMERS, hold nothing but the 64 cs x 32 cb x 9 accumulator block (72 registers) and feed the matrix
+//     cores out of the current LDS tile buffer (wave w: cs-tiles {2*(w&1), +1} x cb-tile (w>>1) x 9 taps, 22 transposed reads
+//     per 18 MFMAs);
+//   * waves 4-11, the PRODUCERS, hold nothing but raw 16-byte pieces: they keep the NEXT TWO tiles in flight in two register
+//     sets (a piece has two whole steps to arrive), apply the load transforms of tile t+1 on the VALU while the consumers
+//     multiply tile t, write it to the idle LDS buffer and re-issue that register set for tile t+3.
+//   So every SIMD runs one matrix wave beside two VALU / memory waves, every CU always has about two tiles (100-180 KB) in
+//   flight, and neither role needs more than a third of the register file.  One barrier per tile.
+//   * the block is written ONCE per workgroup as an fp32 partial already in the reference layout [cs][cb][3][3] (through an LDS
+//     image: whole 1152-byte rows, 16-byte stores); the partials of the position slices are summed in slice order by
+//     reduce_slices_kernel (deterministic, no atomics, no permutation pass).
+#pragma once
+#include "eae_common.hip.h"
+#include "eae_igemm.hip.h"
+
+struct WgradArgs {
+  SrcDesc small, big;
+  float* part;            // [nslices][CS][CB][9]
+  int B, Hs, Ws;          // small-map spatial size (big map = 2Hs x 2Ws)
+  int tiles_per_block, ntiles, nslices;
+};
+
+constexpr int S_STRIDE = 72;   // bf16 elements per staged S row: 64 channels + 8 pad (144 B)
+constexpr int WG_EP_STRIDE = 292;   // floats per cs row of the epilogue image [64][32*9 (+4)]: 16-byte rows, conflict-free 4-byte writes
+constexpr int WG_THREADS = 768, WG_PRODUCERS = 512;
+
+template <int TW, int TH, int NI>
+struct WgGeo {
+  static constexpr int PH = 2 * TH + 1, PW = 2 * TW + 1, NPIX = NI * PH * PW;
+  static constexpr int NPA = (NPIX * 4 + WG_PRODUCERS - 1) / WG_PRODUCERS;        // patch pieces per producer thread
+  static constexpr int BUF_ELEMS = NPIX * PIX_STRIDE + 128 * S_STRIDE;            // bf16 elements of one tile buffer (patch + S)
+  static constexpr size_t smem() {
+    size_t tiles = (size_t)2 * BUF_ELEMS * 2, ep = (size_t)64 * WG_EP_STRIDE * 4;
+    return tiles > ep ? tiles : ep;
+  }
+};
+
+// raw 16-byte pieces of one tile as they come back from memory, plus their validity (zero padding / images past the batch)
+template <int NPA, int SMODE, int BMODE>
+struct WgRaw {
+  RawPiece<BMODE> b[NPA];
+  RawPiece<SMODE> s[2];
+  bool bval[NPA], sval[2];
+};
+
+template <int CS, int CB, int TW, int TH, int NI, int SMODE, int BMODE>
+__global__ __launch_bounds__(WG_THREADS, 3) void wgrad_s2_kernel(WgradArgs a) {
+  static_assert(NI * TH * TW == 128, "tile must hold 128 positions");
+  static_assert(CS % 64 == 0 && CB % 32 == 0, "shape");
+  using G = WgGeo<TW, TH, NI>;
+  constexpr int PH = G::PH, PW = G::PW, NPIX = G::NPIX, NPA = G::NPA;
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);      // 0..11, wave-uniform by construction
+  // workgroup -> (position slice, output block): the (CS/64)*(CB/32) output blocks of one slice read the same tiles, so they
+  // sit on the same XCD, adjacent in dispatch order (ids go round-robin over the 8 XCDs), and share them through that L2
+  constexpr int NBLK = (CS / 64) * (CB / 32);
+  int slice, oblk;
+  {
+    const int bid = blockIdx.x;
+    if (NBLK == 1) { slice = bid; oblk = 0; }
+    else if (a.nslices % 8 == 0) { const int xcd = bid & 7, idx = bid >> 3; oblk = idx % NBLK; slice = (idx / NBLK) * 8 + xcd; }
+    else { oblk = bid % NBLK; slice = bid / NBLK; }
+  }
+  const int cs0 = (oblk / (CB / 32)) * 64, cb0 = (oblk % (CB / 32)) * 32;
+  const int t_first = slice * a.tiles_per_block;
+  int t_end = t_first + a.tiles_per_block;
+  if (t_end > a.ntiles) t_end = a.ntiles;
+  const int n = t_end > t_first ? t_end - t_first : 0;          // tiles of this workgroup (same for all its waves)
+  bf16_t* buf0 = smem;
+  bf16_t* buf1 = smem + G::BUF_ELEMS;
+  float* ep = reinterpret_cast<float*>(smem);                   // epilogue image, aliases the tile buffers
+
+  if (wave >= 4) {
+    // ================================================================ producers (512 threads)
+    const int tid = threadIdx.x - 256;
+    const int Hb = a.Hs * 2, Wb = a.Ws * 2;
+    const int tiles_x = a.Ws / TW, tiles_y = a.Hs / TH;
+    const int kgs4 = tid & 3, kgs8 = tid & 7;
+    ChanCoef<BMODE> ccb;
+    ccb.load(a.big.coef, CB, cb0 + kgs4 * 8);
+    ChanCoef<SMODE> ccs;
+    ccs.load(a.small.coef, CS, cs0 + kgs8 * 8);
+    SrcRsrc rsb, rss;
+    rsb.init<BMODE>(a.big);
+    rss.init<SMODE>(a.small);
+    using Raw = WgRaw<NPA, SMODE, BMODE>;
+    auto issue = [&](Raw& r, int t) __attribute__((always_inline)) {        // request the raw pieces of tile t
+      // the piece -> (image, row, column) arithmetic is redone per call on an opaque copy of the thread index: hoisted out of
+      // the tile loop it costs ~20 registers per lane, which pushes prefetched pieces into scratch (and a scratch reload behind
+      // the prefetch would wait for it: vector-memory results return in issue order)
+      int tq = tid;
+      asm volatile("" : "+v"(tq));
+      const int txb = t % tiles_x; t /= tiles_x;
+      const int tyb = t % tiles_y; t /= tiles_y;
+      const int img0 = t * NI;
+      const int iy0 = 2 * tyb * TH - 1, ix0 = 2 * txb * TW - 1;
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) {         // big-map patch (32 channels cb0..cb0+31)
+        const int pix = (tq + i * WG_PRODUCERS) >> 2;
+        const int img = pix / (PH * PW), rem = pix % (PH * PW);
+        const int pr = rem / PW, pc = rem % PW;
+        const int iy = iy0 + pr, ix = ix0 + pc, nn = img0 + img;
+        r.bval[i] = (pix < NPIX) && (nn < a.B) && (iy >= 0) && (iy < Hb) && (ix >= 0) && (ix < Wb);
+        const uint32_t off = ((uint32_t)((nn * Hb + iy) * Wb + ix) * CB + cb0 + kgs4 * 8) * 2u;
+        load_piece_b<BMODE>(rsb, r.bval[i] ? off : OOB_OFF, r.b[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {           // small-map tile [128 positions][64 channels cs0..]
+        const int m = (tq + i * WG_PRODUCERS) >> 3;
+        const int img = m / (TH * TW), ty = (m / TW) % TH, tx = m % TW;
+        const int nn = img0 + img;
+        r.sval[i] = nn < a.B;
+        const uint32_t off = ((uint32_t)((nn * a.Hs + tyb * TH + ty) * a.Ws + txb * TW + tx) * CS + cs0 + kgs8 * 8) * 2u;
+        load_piece_b<SMODE>(rss, r.sval[i] ? off : OOB_OFF, r.s[i]);
+      }
+    };
+    auto stage = [&](const Raw& r, bf16_t* buf) __attribute__((always_inline)) {   // load transforms, once per element, into a tile buffer
+      bf16_t* patch = buf;
+      bf16_t* sl = buf + NPIX * PIX_STRIDE;
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) {
+        const int qq = tid + i * WG_PRODUCERS;
+        if (qq < NPIX * 4)
+          *reinterpret_cast<uint4*>(patch + (qq >> 2) * PIX_STRIDE + kgs4 * 8) = transform_piece<BMODE>(r.b[i], r.bval[i], ccb);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int qq = tid + i * WG_PRODUCERS;
+        *reinterpret_cast<uint4*>(sl + (qq >> 3) * S_STRIDE + kgs8 * 8) = transform_piece<SMODE>(r.s[i], r.sval[i], ccs);
+      }
+    };
+    Raw ra, rb;
+    if (n > 0) {
+      issue(ra, t_first);
+      if (n > 1) issue(rb, t_first + 1);
+      stage(ra, buf0);
+      if (n > 2) issue(ra, t_first + 2);
+    }
+    __syncthreads();                                  // tile 0 staged
+    // step t (consumers multiply tile t): stage tile t+1 into the idle buffer, then re-issue its register set for tile t+3
+    for (int t = 0; t < n; t += 2) {
+      if (t + 1 < n) { stage(rb, buf1); if (t + 3 < n) issue(rb, t_first + t + 3); }
+      __syncthreads();
+      if (t + 1 < n) {
+        if (t + 2 < n) { stage(ra, buf0); if (t + 4 < n) issue(ra, t_first + t + 4); }
+        __syncthreads();
+      }
+    }
+    __syncthreads();                                  // consumers have written the epilogue image
+  } else {
+    // ================================================================ consumers (256 threads)
+    const int it0 = 2 * (wave & 1), jt = wave >> 1;
+    f32x4 acc[9][2];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) acc[t9][0] = acc[t9][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    // Fragment addresses = (lane part, computed once) + (compile-time part of the K-step and the tap, folded into the ds_read
+    // immediate): a K-step is 32 consecutive positions, so position m = 32*ks + ml with ml = 8g+q (+4) < 32 never carries
+    // into the K-step part of (image, row, column).
+    auto pix_of = [](int m) { const int img = m / (TH * TW), ty = (m / TW) % TH, tx = m % TW; return (img * PH + 2 * ty) * PW + 2 * tx; };
+    const int ml = 8 * g + q;
+    const int s_lo = ml * S_STRIDE + it0 * 16 + 4 * p, s_hi = s_lo + 4 * S_STRIDE;
+    const int p_lo = pix_of(ml) * PIX_STRIDE + jt * 16 + 4 * p, p_hi = pix_of(ml + 4) * PIX_STRIDE + jt * 16 + 4 * p;
+    auto mfma_tile = [&](const bf16_t* buf) __attribute__((always_inline)) {   // 4 K-steps of 32 positions
+      const bf16_t* patch = buf;
+      const bf16_t* sl = buf + NPIX * PIX_STRIDE;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        constexpr int dummy = 0; (void)dummy;
+        const int pk = ((ks * 32) / (TH * TW) * PH + 2 * (((ks * 32) / TW) % TH)) * PW + 2 * ((ks * 32) % TW);   // pix_of(32*ks), compile time
+        bf16x8 sa[2];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+          sa[ii] = tr_frag(sl + s_lo + ks * 32 * S_STRIDE + ii * 16, sl + s_hi + ks * 32 * S_STRIDE + ii * 16);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int toff = (tap / 3) * PW + (tap % 3);
+          bf16x8 bb = tr_frag(patch + p_lo + (pk + toff) * PIX_STRIDE, patch + p_hi + (pk + toff) * PIX_STRIDE);
+          acc[tap][0] = mfma16(sa[0], bb, acc[tap][0]);
+          acc[tap][1] = mfma16(sa[1], bb, acc[tap][1]);
+        }
+      }
+    };
+    __syncthreads();                                  // tile 0 staged
+    for (int t = 0; t < n; t += 2) {
+      mfma_tile(buf0);
+      __syncthreads();
+      if (t + 1 < n) {
+        mfma_tile(buf1);
+        __syncthreads();
+      }
+    }
+    // epilogue image [64 cs][32 cb * 9 taps] (the loop ended with a barrier: every wave is done with the tile buffers)
+    const int ecb = (jt * 16 + (lane & 15)) * 9;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ep[((it0 + ii) * 16 + (lane >> 4) * 4 + r) * WG_EP_STRIDE + ecb + tap] = acc[tap][ii][r];
+    __syncthreads();
+  }
+  // ---- whole 1152-byte rows of the partial go out with 16-byte stores, already in the reference layout
+  float* out = a.part + (size_t)slice * ((size_t)CS * CB * 9) + (size_t)cs0 * (CB * 9) + cb0 * 9;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {          // 64 rows x 72 float4 = 4608 = 6 x 768
+    const int e = (int)threadIdx.x + i * WG_THREADS;
+    const int row = e / 72, c4 = e % 72;
+    *reinterpret_cast<float4*>(out + (size_t)row * (CB * 9) + c4 * 4) = *reinterpret_cast<const float4*>(ep + row * WG_EP_STRIDE + c4 * 4);
+  }
+}
+
+// Deterministic slice reductions: block = 16 float4 lanes x 16 slice lanes; every thread sums its slices in order, then
+// the 16 slice lanes are combined in a fixed order through LDS.
+template <class Store>
+__device__ __forceinline__ void reduce_slices_body(const float* __restrict__ part, int nslices, long n4, Store store) {
+  __shared__ float4 red[16][16];
+  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + lx;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4)
+    for (int sidx = ly; sidx < nslices; sidx += 16) {
+      float4 v = reinterpret_cast<const float4*>(part)[(long)sidx * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  red[ly][lx] = s;
+  __syncthreads();
+  if (ly == 0 && i < n4) {
+    float4 r = red[0][lx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { r.x += red[k][lx].x; r.y += red[k][lx].y; r.z += red[k][lx].z; r.w += red[k][lx].w; }
+    store(i, r);
+  }
+}
+
+// out[i] = sum_s part[s][i]
+static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ part, int nslices, long n4,
+                                                                   float* __restrict__ out, float scale) {
+  reduce_slices_body(part, nslices, n4, [=](long i, float4 r) {
+    r.x *= scale; r.y *= scale; r.z *= scale; r.w *= scale;
+    reinterpret_cast<float4*>(out)[i] = r;
+  });
+}
+
+static inline unsigned reduce_slices_grid(long n4) { return (unsigned)((n4 + 15) / 16); }
+
+// Tall variant for few outputs and many slices (conv1 / deconv4 weight gradients: 216 float4, 512 slices): 4 float4 columns
+// x 64 slice lanes per block -> 4x the blocks and a quarter of the serial loads per thread; fixed summation order.
+static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_tall_kernel(const float* __restrict__ part, int nslices, long n4,
+                                                                                float* __restrict__ out) {
+  __shared__ float4 red[64][4];
+  const int lx = threadIdx.x & 3, ly = threadIdx.x >> 2;
+  const long i = (long)blockIdx.x * 4 + lx;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4)
+    for (int sidx = ly; sidx < nslices; sidx += 64) {
+      float4 v = reinterpret_cast<const float4*>(part)[(long)sidx * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  red[ly][lx] = s;
+  __syncthreads();
+  if (ly == 0 && i < n4) {
+    float4 r = red[0][lx];
+    for (int k = 1; k < 64; ++k) { r.x += red[k][lx].x; r.y += red[k][lx].y; r.z += red[k][lx].z; r.w += red[k][lx].w; }
+    reinterpret_cast<float4*>(out)[i] = r;
+  }
+}

@@ -1,6 +1,6 @@
 // Host-side dispatch of the generic 3x3 stride-2 weight-gradient kernel.
 #include "eae_internal.h"
-#include "eae_wgrad.cuh"
+#include "eae_wgrad.hip.h"
 
 namespace {
 template <int CS, int CB, int TW, int TH, int NI, int SM, int BM>
@@ -8,9 +8,9 @@ int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_fl
   WgradArgs a = a0;
   constexpr int nblk = (CS / 64) * (CB / 32);
   constexpr long long sz = (long long)CS * CB * 9;
-  // 128 workgroups (half the CUs, 8 tiles each at B=512): the kernel runs beside the backward-data chain, and a grid that blankets
-  // every CU with 256-register waves leaves those kernels no SIMD to land on (128: 0.575, 256: 0.579, 64: 0.62 ms/step)
-  static const int wgs = getenv("EAE_WGRAD_WGS") ? atoi(getenv("EAE_WGRAD_WGS")) : 128;
+  // One 12-wave workgroup per CU (4 consumer + 8 producer waves).  EAE_WGRAD_WGS workgroups in all: every one writes a partial of
+  // its 64 x 32 x 9 block, so the count also sets the split-K traffic.
+  static const int wgs = getenv("EAE_WGRAD_WGS") ? atoi(getenv("EAE_WGRAD_WGS")) : 256;
   int slices = wgs / nblk;
   if (slices < 1) slices = 1;
   if (slices > ntiles) slices = ntiles;
@@ -22,15 +22,11 @@ int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_fl
   a.part = scratch;
   a.nslices = slices;
   auto kern = wgrad_s2_kernel<CS, CB, TW, TH, NI, SM, BM>;
-  constexpr size_t smem = wgrad_smem<TW, TH, NI>();
-  static bool done = false;
-  if (!done) {
-    EAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(slices * nblk), dim3(256), smem, st, a);
+  constexpr size_t smem = WgGeo<TW, TH, NI>::smem();
+  EAE_HIP(eae_smem_attr(reinterpret_cast<const void*>(kern), smem));
+  hipLaunchKernelGGL(kern, dim3(slices * nblk), dim3(WG_THREADS), smem, st, a);
   EAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_slices_perm_kernel, dim3(reduce_slices_grid(sz / 4)), dim3(256), 0, st, scratch, slices, CS, CB, dw);
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(sz / 4)), dim3(256), 0, st, scratch, slices, (long)(sz / 4), dw, 1.0f);
   EAE_LAUNCH_CHECK();
   return 0;
 }
