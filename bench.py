@@ -41,67 +41,80 @@ def make_batch(b, device, seed):
     return x.to(device), y.to(device)
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """The CPU restatement (oracle/ae_torch_cpu.py, same module graph as the reference notebook, fp32, torch CPU ops on
-    all host cores) timed on a bounded sample: B=64 (the notebook's batch size, R.md:246) train steps."""
-    from oracle import ae_torch_cpu as T
-    # host cores actually available to this job: the GPU boxes expose 256 logical CPUs but a 1-GPU job owns a 16-core
-    # share; oversubscribing the OpenMP pool makes the torch CPU ops orders of magnitude slower
+def host_cores():
+    """(cores this job may use, logical CPUs visible, cgroup quota in cores or None).  The GPU boxes expose every logical CPU of
+    the host to a 1-GPU job but give it a CPU-time quota (cgroup cpu.max) of a 16-core share; an OpenMP pool wider than the quota
+    makes the torch CPU ops many times slower, so the thread count is min(visible, quota)."""
     try:
-        avail = len(os.sched_getaffinity(0))
+        visible = len(os.sched_getaffinity(0))
     except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = int(os.environ.get("EAE_CPU_THREADS", min(avail, 16)))
-    torch.set_num_threads(cores)
-    model = T.build(latent_dim=64, seed=0)
-    opt = T.make_adam(model, LR)
-    g = torch.Generator().manual_seed(1234)
-    x = torch.rand((64, 3, 64, 64), generator=g)
-    y = torch.randint(0, 10, (64,), generator=g)
-    T.train_step(model, opt, x, y, ALPHA)       # warm-up (allocations, thread pool)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        T.train_step(model, opt, x, y, ALPHA)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 5000:
+        visible = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
             break
-    return {"value": round(64 * n / el, 1), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n} train steps of batch 64 (fp32, torch CPU ops, oracle/ae_torch_cpu.py)"}
+        except Exception:
+            continue
+    cores = visible if quota is None else max(1, min(visible, int(quota + 0.5)))
+    return cores, visible, quota
+
+
+def cpu_baseline(seconds_budget=10.0):
+    """The CPU restatement (oracle/ae_torch_cpu.py, same module graph as the reference notebook, fp32, torch CPU ops on the
+    host cores this job may use) timed on bounded samples of the same train step: B=32 (BASELINE configs[0]) and B=64 (the
+    notebook's batch size, R.md:246), SURVEY.md 8d.  `value` is the B=64 leg."""
+    from oracle import ae_torch_cpu as T
+    cores, visible, quota = host_cores()
+    cores = int(os.environ.get("EAE_CPU_THREADS", cores))
+    torch.set_num_threads(cores)
+    legs = {}
+    for b in (32, 64):
+        model = T.build(latent_dim=64, seed=0)
+        opt = T.make_adam(model, LR)
+        g = torch.Generator().manual_seed(1234)
+        x = torch.rand((b, 3, 64, 64), generator=g)
+        y = torch.randint(0, 10, (b,), generator=g)
+        T.train_step(model, opt, x, y, ALPHA)       # warm-up (allocations, thread pool)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            T.train_step(model, opt, x, y, ALPHA)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > seconds_budget or n >= 5000:
+                break
+        legs[f"b{b}"] = {"images_per_s": round(b * n / el, 1), "ms_per_step": round(1e3 * el / n, 2), "steps": n}
+    return {"value": legs["b64"]["images_per_s"], "unit": "images/s", "cores": cores, "kind": "port",
+            "host_cpus_visible": visible, "cgroup_quota_cores": quota,
+            "sample": f"{legs['b64']['steps']} train steps of batch 64 and {legs['b32']['steps']} of batch 32 (fp32, torch CPU ops, "
+                      f"{cores} threads, oracle/ae_torch_cpu.py)",
+            "legs": legs}
 
 
 def kernel_roofline(eng, step_fn, batch):
-    """Per-launch duration of the dominant kernel measured with HIP events on the launch stream inside real train steps,
-    priced against its bounding roofline with ALGORITHMIC bytes (DESIGN.md section 'Roofline accounting')."""
+    """Per-launch duration of the DOMINANT kernel -- the one with the largest total duration in the newest committed rocprofv3
+    summary under profiles/ -- measured live with HIP events on the stream it is launched on inside real train steps, priced
+    against its bounding roofline with its own ALGORITHMIC bytes."""
     from eae_amd import profile_hooks as PH
-    r = PH.dominant_kernel_roofline(eng, step_fn, batch, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFLOPS)
-    # HBM traffic of that kernel from the PMC counters: collected with rocprofv3 in separate --pmc passes of this same
-    # command (they cannot be read from inside the process) and committed under profiles/
-    kname = "void igemm_s2_kernel<0, 32, 64, 64, 16, 8, 1, 1, 0>(ConvArgs)"
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_b512.json")
-    if batch == BATCH and os.path.exists(pmc):
-        k = json.load(open(pmc))["kernels"].get(kname)
-        if k:
-            r["traffic"] = k["traffic_bytes"]
-    # The committed rocprofv3 --kernel-trace --stats summary of this same command (profiles/) is the cross-check: its average
-    # for this kernel includes the command processor's dispatch/completion overhead (an empty kernel reads >= 2 us there), so
-    # it sits above the calibrated event time.  `achieved` is priced on the SLOWER of the two, so the claim never exceeds what
-    # the committed profile supports.
-    import csv
-    import glob
-    stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_b512_kernel_stats_v*.csv")),
-                   key=lambda p: int(p.rsplit("_v", 1)[1].split(".")[0]))
-    if batch == BATCH and stats:
-        for row in csv.DictReader(open(stats[-1])):
-            if row["Name"] == kname:
-                r["rocprof_avg_us"] = round(float(row["AverageNs"]) / 1e3, 2)
-                r["rocprof_summary"] = os.path.relpath(stats[-1], ROOT)
-    us = max(r["avg_launch_us"], r.get("rocprof_avg_us", 0.0))
-    r["priced_us"] = us
-    r["achieved"] = round(r["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9, 1)
-    r["frac"] = round(r["achieved"] / HBM_PEAK_GBS, 4)
-    r["tflops"] = round(batch * PH.CONV2_FLOP_PER_IMG / (us * 1e-6) / 1e12, 1)
-    return r
+    return PH.dominant_kernel_roofline(eng, step_fn, batch, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFLOPS)
+
+
+def time_steps(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
 
 
 def main():
@@ -112,6 +125,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configs[1] measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,6 +214,19 @@ def main():
                 out["roofline"] = kernel_roofline(eng, lambda: eng.train_step(x, y, ALPHA, LR), args.batch)
             except Exception as e:  # the headline number must still be printed
                 out["roofline"] = {"error": str(e)[:200]}
+        if world == 1 and not args.no_configs:
+            # the other single-GPU BASELINE config, measured the same way (not the headline: parity-tested in tests/):
+            # configs[1] = batch 256, encoder + decoder reconstruction (MSE) only
+            try:
+                x2, y2 = x[:256].contiguous(), y[:256].contiguous()
+                sec = time_steps(lambda: eng.train_step(x2, y2, 1.0, LR, head=False), min(args.steps, 200), min(args.warmup, 20))
+                b2 = 256 * (BYTES_PER_IMG_BF16 - 0.0) + BYTES_PER_STEP_WEIGHTS
+                out["configs"] = {"c2": {"workload": "BASELINE configs[1]: batch 256, encoder+decoder reconstruction (MSE) only, bf16",
+                                         "ms_per_step": round(1e3 * sec, 4), "images_per_s": round(256 / sec, 1),
+                                         "hbm_floor_us": round(b2 / (HBM_PEAK_GBS * 1e3), 1),
+                                         "frac_of_hbm_floor": round(b2 / (HBM_PEAK_GBS * 1e3) / (sec * 1e6), 4)}}
+            except Exception as e:
+                out["configs"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

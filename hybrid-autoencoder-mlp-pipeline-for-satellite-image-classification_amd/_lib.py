@@ -22,6 +22,9 @@ class EaeStepIO(C.Structure):
                 ("x_hat", vp), ("logits", vp), ("z", vp), ("loss_accum", vp), ("loss_last", vp)]
 
 
+SYNC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p)
+
+
 class EaeSrc(C.Structure):
     _fields_ = [("p0", vp), ("p1", vp), ("coef", vp), ("mode", C.c_int)]
 
@@ -37,7 +40,8 @@ _PROTOS = {
     "eae_set_adam_step": (C.c_int, [vp, C.c_longlong]),
     "eae_get_adam_step": (C.c_longlong, [vp]),
     "eae_ae_forward": (C.c_int, [vp, vp, C.POINTER(EaeStepIO)]),
-    "eae_ae_backward": (C.c_int, [vp, vp, vp, vp, vp, vp]),
+    "eae_forward_generation": (C.c_longlong, [vp]),
+    "eae_ae_backward": (C.c_int, [vp, vp, C.c_longlong, vp, vp, vp, vp, vp]),
     "eae_ae_grad_step": (C.c_int, [vp, vp, C.POINTER(EaeStepIO)]),
     "eae_adam_step": (C.c_int, [vp, vp, C.c_float, C.c_float]),
     "eae_ae_grad_step_begin": (C.c_int, [vp, vp, C.POINTER(EaeStepIO)]),
@@ -46,6 +50,8 @@ _PROTOS = {
     "eae_dp_stream": (vp, [vp, C.c_int]),
     "eae_adam_step_scaled": (C.c_int, [vp, vp, C.c_float, C.c_float, C.c_float]),
     "eae_ae_train_step": (C.c_int, [vp, vp, C.POINTER(EaeStepIO), C.c_float]),
+    "eae_sync_bn_acc_elems": (C.c_longlong, [vp]),
+    "eae_set_sync_bn": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     "eae_encoder_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "eae_decoder_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "eae_debug_copy": (C.c_int, [vp, C.c_int, vp, C.c_longlong]),
@@ -53,7 +59,7 @@ _PROTOS = {
     "eae_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), c_ll_p]),
     "eae_profile_read2": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), c_ll_p]),
     "eae_op_conv_s2": (C.c_int, [vp, C.c_int, EaeSrc, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]),
-    "eae_op_conv_s2_ntiles": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "eae_op_conv_s2_ntiles": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "eae_op_edge_conv": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]),
     "eae_op_edge_wgrad": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, EaeSrc, vp, C.c_longlong, vp]),
     "eae_op_deconv4_loss": (C.c_int, [vp, EaeSrc, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_float, vp, vp, vp]),

@@ -101,5 +101,29 @@ def scan_packed_fp32(lib=LIB, objdump="/opt/rocm/lib/llvm/bin/llvm-objdump"):
     return total, opsel
 
 
+def scan_packed_fp32_rccl(objdump="/opt/rocm/lib/llvm/bin/llvm-objdump", bundler="/opt/rocm/lib/llvm/bin/clang-offload-bundler",
+                          objcopy="/opt/rocm/lib/llvm/bin/llvm-objcopy"):
+    """The same census for the gfx950 code of the librccl.so that torch loads (its collectives run beside the MFMA kernels when
+    EAE_DP_OVERLAP=1).  The library keeps a COMPRESSED offload bundle: .hip_fatbin is dumped, unbundled for gfx950 and
+    disassembled in a stream (277 MB of code: about 3 minutes, 1 GB of scratch files under $TMPDIR).
+    Returns (v_pk_*_f32 total, with `op_sel:`, with `op_sel_hi:`).  torch 2.10.0+rocm7.0: (325, 0, 168)."""
+    import re
+    import tempfile
+    import torch
+    lib = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "rccl.fatbin"), os.path.join(d, "rccl_gfx950.co")
+        subprocess.run([objcopy, "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(d, "dummy.so")], check=True)
+        subprocess.run([bundler, "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"], check=True)
+        total = opsel = opsel_hi = 0
+        with subprocess.Popen([objdump, "-d", "--mcpu=gfx950", co], stdout=subprocess.PIPE, text=True) as pr:
+            for line in pr.stdout:
+                if re.search(r"\bv_pk_\w+_f32\b", line):
+                    total += 1
+                    opsel += "op_sel:" in line
+                    opsel_hi += "op_sel_hi:" in line
+    return total, opsel, opsel_hi
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

@@ -5,6 +5,7 @@
 #include "eae_edge.hip.h"
 #include "eae_wgrad.hip.h"
 #include "eae_fc.hip.h"
+#include <functional>
 #include <string>
 #include <vector>
 #include <cmath>
@@ -63,7 +64,8 @@ struct eae_ctx {
   bool packed = false;
   bool fwd_ready = false;          // a train-mode forward with gradient staging is resident in the workspace
   int fwd_B = 0, fwd_head = 0;
-  const float* fwd_x = nullptr;
+  const float* fwd_x = nullptr;    // only used between eae_ae_grad_step_begin / _end (the caller keeps the batch alive in between)
+  long long fwd_gen = 0;           // bumped by every forward: eae_ae_backward refuses to differentiate a forward that is no longer resident
   // workspace
   void* ws = nullptr;
   bf16_t *y[4], *u[3], *d0, *gy[4], *gu[3], *gd0, *g4;
@@ -94,6 +96,13 @@ struct eae_ctx {
   uint8_t* acc_base = nullptr;
   size_t acc_bytes = 0;
   bool acc_clean = false;          // all zero (cleared by the engine's own Adam launch or at creation)
+  // synchronized BatchNorm across data-parallel replicas (eae_set_sync_bn): the batch statistics of every BN layer are summed
+  // over the replicas through the caller's hook (forward: the fixed-point accumulators; backward: the fp64 sums) before the
+  // consumers turn them into coefficients with the GLOBAL element count
+  int sync_world = 1;
+  eae_sync_fn sync_fn = nullptr;
+  void* sync_user = nullptr;
+  double* sync_sums = nullptr;     // caller-owned device buffer [7][2][256] fp64
   bool fold_fwd = true;
   bool side_forked = false;        // `side` already waits for the current position of the main stream (no kernel enqueued on main since)
   int side_rr = 0;
@@ -121,11 +130,14 @@ struct eae_ctx {
   bool use_graph = true;
   bool capturing = false;
   float* dyn = nullptr;            // device: lr/bc1, sqrt(bc2), weight decay of the current Adam step
-  // optional in-situ timing of the dominant kernel (enc.conv2 forward) with HIP events on the launch stream
+  // optional in-situ timing of ONE launch site (eae_profile_enable(ctx, site); sites: include/eae.h) with HIP events on the
+  // stream that launch goes to
   static constexpr int PROF_RING = 64;
   bool prof_on = false;
+  int prof_site = 0;
   int prof_n = 0;
   hipEvent_t prof_ev[3 * PROF_RING] = {};     // per sample: before, after, after an EMPTY bracket (calibration)
+  EaeProfHook prof_hook = {};
   long long act_elems(int lvl) const {   // per-image elements of the map after `lvl` stride-2 stages (1..4)
     return (long long)(H >> lvl) * (W >> lvl) * ENC_C[lvl];
   }
@@ -171,7 +183,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
     long long t1 = (long long)eae_edge_tiles((int)Bm, c->H, c->W) * 2 * 32;
     long long t2 = (long long)eae_conv_s2_ntiles(0, (int)Bm, c->H / 2, c->W / 2) * 2 * 64;
     long long t3 = ((Bm + 127) / 128) * c->Pn * 2 * 256;
-    long long t4 = (long long)eae_conv_s2_ntiles(1, (int)Bm, c->H / 4, c->W / 4) * 2 * 32;
+    long long t4 = (long long)eae_conv_s2_ntiles(1, (int)Bm, c->H / 4, c->W / 4, 64) * 2 * 32;
     long long t5 = (long long)eae_conv_s2_ntiles(1, (int)Bm, c->H / 8, c->W / 8) * 2 * 64 + (long long)Bm * 2 * 256;
     stat_floats = std::max(std::max(t1, t2), std::max(t3, std::max(t4, t5))) + 1024;
   }
@@ -191,7 +203,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
     const int Bi = (int)Bm;
     const int nt[7] = {eae_edge_tiles(Bi, c->H, c->W), eae_conv_s2_ntiles(0, Bi, c->H / 2, c->W / 2), eae_conv_s2_ntiles(0, Bi, c->H / 4, c->W / 4),
                        eae_conv_s2_ntiles(0, Bi, c->H / 8, c->W / 8), eae_conv_s2_ntiles(1, Bi, c->H / 16, c->W / 16),
-                       eae_conv_s2_ntiles(1, Bi, c->H / 8, c->W / 8), eae_conv_s2_ntiles(1, Bi, c->H / 4, c->W / 4)};
+                       eae_conv_s2_ntiles(1, Bi, c->H / 8, c->W / 8), eae_conv_s2_ntiles(1, Bi, c->H / 4, c->W / 4, 64)};
     for (int l = 0; l < 7; ++l) {
       int cp = 8;
       while (cp < 64 && cp * 2 * 16 <= nt[l]) cp *= 2;        // about one accumulator set per 16 producer workgroups ...
@@ -294,11 +306,13 @@ extern "C" int eae_debug_copy(eae_ctx* c, int which, float* dst, long long n) {
   return 0;
 }
 
-extern "C" int eae_profile_enable(eae_ctx* c, int on) {
+extern "C" int eae_profile_enable(eae_ctx* c, int site) {
   if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL");
-  if (on && !c->prof_ev[0])
+  if (site < 0 || site >= EAE_PROF_NSITES) return eae_set_error(EAE_ERR_ARG, "profile: unknown launch site");
+  if (site && !c->prof_ev[0])
     for (int i = 0; i < 3 * eae_ctx::PROF_RING; ++i) EAE_HIP(hipEventCreate(&c->prof_ev[i]));
-  c->prof_on = on != 0;
+  c->prof_on = site != 0;
+  c->prof_site = site;
   c->prof_n = 0;
   return 0;
 }
@@ -353,6 +367,21 @@ extern "C" int eae_bind(eae_ctx* c, float* params, float* grads, float* adam_m, 
       EAE_HIP(hipMemset(grads + c->poff[PREBN_BIAS[k]], 0, (size_t)(c->poff[PREBN_BIAS[k] + 1] - c->poff[PREBN_BIAS[k]]) * 4));
   return 0;
 }
+// Synchronized BatchNorm (new work, SURVEY.md 8e "Equivalence to test": R ranks x B/R with SyncBN == 1 rank x B).
+extern "C" long long eae_sync_bn_acc_elems(eae_ctx* c) { return c ? (long long)(c->acc_bytes / 8) : -1; }
+extern "C" int eae_set_sync_bn(eae_ctx* c, int world, eae_sync_fn fn, void* user, void* acc_i64, void* sums_f64) {
+  if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL");
+  if (world <= 1 || !fn) { c->sync_world = 1; c->sync_fn = nullptr; return 0; }
+  if (!acc_i64 || !sums_f64) return eae_set_error(EAE_ERR_ARG, "sync_bn: the accumulator and sums buffers are required");
+  if (!c->fold_fwd) return eae_set_error(EAE_ERR_STATE, "SyncBN needs the folded forward finalize (unset EAE_NO_FOLD_FWD)");
+  // the forward accumulators move into the caller's buffer (same layout), so that the hook can hand tensor views of it to the collective
+  uint8_t* nb = static_cast<uint8_t*>(acc_i64);
+  for (int l = 0; l < 7; ++l) c->accf[l] = reinterpret_cast<unsigned long long*>(nb + (reinterpret_cast<uint8_t*>(c->accf[l]) - c->acc_base));
+  c->acc_base = nb;
+  c->acc_clean = false;
+  c->sync_world = world; c->sync_fn = fn; c->sync_user = user; c->sync_sums = static_cast<double*>(sums_f64);
+  return 0;
+}
 extern "C" int eae_params_changed(eae_ctx* c) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->packed = false; c->fwd_ready = false; return 0; }
 extern "C" int eae_set_adam_step(eae_ctx* c, long long s) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->adam_step = s; return 0; }
 extern "C" long long eae_get_adam_step(eae_ctx* c) { return c ? c->adam_step : -1; }
@@ -360,6 +389,38 @@ extern "C" long long eae_get_adam_step(eae_ctx* c) { return c ? c->adam_step : -
 namespace {
 
 #define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+// HIP-event bracket around ONE launch on the stream it goes to (bench.py's `roofline`): before / after, then an EMPTY bracket
+// recorded right behind it, which measures what the two event records cost by themselves on that stream.
+static void prof_hook_begin(void* u, hipStream_t st) {
+  eae_ctx* c = static_cast<eae_ctx*>(u);
+  hipEventRecord(c->prof_ev[3 * c->prof_n], st);
+}
+static void prof_hook_end(void* u, hipStream_t st) {
+  eae_ctx* c = static_cast<eae_ctx*>(u);
+  hipEventRecord(c->prof_ev[3 * c->prof_n + 1], st);
+  hipEventRecord(c->prof_ev[3 * c->prof_n + 2], st);
+  c->prof_n++;
+}
+// hook for launchers that enqueue a second kernel behind the timed one; nullptr when `site` is not the one being profiled
+static const EaeProfHook* prof_hook_for(eae_ctx* c, int site) {
+  if (!(c->prof_on && c->prof_site == site && c->prof_n < eae_ctx::PROF_RING && !c->capturing)) return nullptr;
+  c->prof_hook = EaeProfHook{prof_hook_begin, prof_hook_end, c};
+  return &c->prof_hook;
+}
+struct ProfBracket {
+  eae_ctx* c; hipStream_t st; bool on;
+  ProfBracket(eae_ctx* c_, int site, hipStream_t st_) : c(c_), st(st_) {
+    on = c->prof_on && c->prof_site == site && c->prof_n < eae_ctx::PROF_RING && !c->capturing;
+    if (on) hipEventRecord(c->prof_ev[3 * c->prof_n], st);
+  }
+  ~ProfBracket() {
+    if (!on) return;
+    hipEventRecord(c->prof_ev[3 * c->prof_n + 1], st);
+    hipEventRecord(c->prof_ev[3 * c->prof_n + 2], st);
+    c->prof_n++;
+  }
+};
 
 // fork: work enqueued on the returned stream starts after everything enqueued so far on `st`
 int fork_side(eae_ctx* c, hipStream_t st, hipStream_t* out) {
@@ -369,21 +430,6 @@ int fork_side(eae_ctx* c, hipStream_t st, hipStream_t* out) {
   EAE_HIP(hipEventRecord(ev, st));
   EAE_HIP(hipStreamWaitEvent(c->side, ev, 0));
   *out = c->side;
-  return 0;
-}
-// fork for a weight-gradient group (wgrad + its slice reduction): the groups go round-robin over the side streams, each
-// with its own split-K scratch, so the reduction of one layer runs beside the wgrad kernels of the next ones
-int fork_wgrad(eae_ctx* c, hipStream_t st, hipStream_t* out, float** scratch) {
-  *scratch = c->wscratch;
-  if (!c->use_side || c->nx == 0) return fork_side(c, st, out);
-  const int k = c->side_rr++ % (c->nx + 1);
-  if (k == 0) return fork_side(c, st, out);
-  hipEvent_t ev = c->ev_fork[c->ev_i];
-  c->ev_i = (c->ev_i + 1) % eae_ctx::NEV;
-  EAE_HIP(hipEventRecord(ev, st));
-  EAE_HIP(hipStreamWaitEvent(c->sidex[k - 1], ev, 0));
-  *out = c->sidex[k - 1];
-  *scratch = c->wscratchx[k - 1];
   return 0;
 }
 // everything enqueued so far on the extra side streams completes before later work on the first one (the DP path hands
@@ -429,9 +475,20 @@ void fold_producer(eae_ctx* c, ConvArgs& a, int l, bool train) {
   a.stat_part = nullptr;
 }
 // consumer side: coefficient table of BN layer l from its accumulators
+// SyncBN: sum layer l's forward accumulators over the replicas (order-independent integer sums: every replica ends with the
+// same bits) between its producer and its first consumer
+int sync_fwd(eae_ctx* c, hipStream_t st, int l, bool train) {
+  if (!train || c->sync_world <= 1) return 0;
+  if (!c->fold_fwd) return eae_set_error(EAE_ERR_STATE, "SyncBN needs the folded forward finalize (unset EAE_NO_FOLD_FWD)");
+  const long long off = (long long)(c->accf[l] - reinterpret_cast<unsigned long long*>(c->acc_base));
+  if (c->sync_fn(c->sync_user, 0, off, (long long)c->acc_copies[l] * 2 * BN_C[l], (void*)st) != 0)
+    return eae_set_error(EAE_ERR_STATE, "SyncBN: the exchange hook failed (forward statistics)");
+  return 0;
+}
 void fold_consumer(eae_ctx* c, BnFold& f, int l, long long count, bool train) {
   f = BnFold();
   if (!train || !c->fold_fwd) return;
+  count *= c->sync_world;
   f.acc = c->accf[l]; f.copies = c->acc_copies[l]; f.inv_scale = 1.0f / ACC_SCALE_FWD; f.count = (float)count;
   f.momentum = BN_MOM; f.eps = BN_EPS;
   f.gamma = c->P + c->poff[BN_GAMMA_IDX[l]]; f.beta = c->P + c->poff[BN_GAMMA_IDX[l] + 1];
@@ -459,6 +516,13 @@ int bn_fwd_finalize(eae_ctx* c, hipStream_t st, int l, int ntiles, long long cou
 }
 
 int bn_bwd_fin(eae_ctx* c, hipStream_t st, int l, int ntiles, long long count) {
+  if (c->sync_world > 1) {
+    double* sums = c->sync_sums + (size_t)l * 512;
+    RC(eae_launch_bn_bwd_reduce(st, c->stat, ntiles, BN_C[l], sums, c->G + c->poff[BN_GAMMA_IDX[l]], c->G + c->poff[BN_GAMMA_IDX[l] + 1]));
+    if (c->sync_fn(c->sync_user, 1, (long long)l * 512, 2LL * BN_C[l], (void*)st) != 0)
+      return eae_set_error(EAE_ERR_STATE, "SyncBN: the exchange hook failed (backward sums)");
+    return eae_launch_bn_bwd_coef(st, sums, BN_C[l], count * c->sync_world, c->P + c->poff[BN_GAMMA_IDX[l]], c->coef_f[l], c->coef_b[l]);
+  }
   return eae_launch_bn_bwd_finalize(st, c->stat, ntiles, BN_C[l], count, c->P + c->poff[BN_GAMMA_IDX[l]], c->coef_f[l],
                                     c->G + c->poff[BN_GAMMA_IDX[l]], c->G + c->poff[BN_GAMMA_IDX[l] + 1], c->coef_b[l]);
 }
@@ -474,6 +538,7 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
     a.c.stat_part = train ? c->stat : nullptr; a.c.B = B;
     fold_producer(c, a.c, 0, train);
     RC(eae_launch_edge_conv(st, SRC3_NCHW_F32, EPI_FWD, a));
+    RC(sync_fwd(c, st, 0, train));
     RC(bn_fwd_finalize(c, st, 0, eae_edge_tiles(B, H, W), (long long)B * (H / 2) * (W / 2), train));
   }
   for (int i = 1; i < 4; ++i) {
@@ -484,14 +549,11 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
     a.B = B; a.Hin = H >> i; a.Win = W >> i;
     fold_producer(c, a, i, train);
     fold_consumer(c, a.fold, i - 1, (long long)B * a.Hin * a.Win, train);
-    const bool prof = c->prof_on && i == 1 && c->prof_n < eae_ctx::PROF_RING;
-    if (prof) EAE_HIP(hipEventRecord(c->prof_ev[3 * c->prof_n], st));
-    RC(eae_launch_conv_s2(a, ENC_C[i], ENC_C[i + 1], SRC_BNRELU, EPI_FWD, st));
-    if (prof) {     // second pair with nothing in between: what two event records cost by themselves on this stream
-      EAE_HIP(hipEventRecord(c->prof_ev[3 * c->prof_n + 1], st));
-      EAE_HIP(hipEventRecord(c->prof_ev[3 * c->prof_n + 2], st));
-      c->prof_n++;
+    {
+      ProfBracket pb(c, i == 1 ? EAE_PROF_CONV2_FWD : -1, st);
+      RC(eae_launch_conv_s2(a, ENC_C[i], ENC_C[i + 1], SRC_BNRELU, EPI_FWD, st));
     }
+    RC(sync_fwd(c, st, i, train));
     RC(bn_fwd_finalize(c, st, i, eae_conv_s2_ntiles(0, B, a.Hin, a.Win), (long long)B * (a.Hin / 2) * (a.Win / 2), train));
   }
   FcNtArgs f = FcNtArgs();
@@ -529,8 +591,12 @@ int run_decoder(eae_ctx* c, hipStream_t st, const float* z, int B, bool train, c
     a.B = B; a.Hin = H >> (4 - i); a.Win = W >> (4 - i);
     fold_producer(c, a, 4 + i, train);
     if (i > 0) fold_consumer(c, a.fold, 3 + i, (long long)B * a.Hin * a.Win, train);
-    RC(eae_launch_deconv_s2(a, cin[i], cin[i] / 2, i == 0 ? SRC_RAW : SRC_BNRELU, EPI_FWD, st));
-    RC(bn_fwd_finalize(c, st, 4 + i, eae_conv_s2_ntiles(1, B, a.Hin, a.Win), (long long)B * (a.Hin * 2) * (a.Win * 2), train));
+    {
+      ProfBracket pb(c, i == 2 ? EAE_PROF_DECONV3_FWD : -1, st);
+      RC(eae_launch_deconv_s2(a, cin[i], cin[i] / 2, i == 0 ? SRC_RAW : SRC_BNRELU, EPI_FWD, st));
+    }
+    RC(sync_fwd(c, st, 4 + i, train));
+    RC(bn_fwd_finalize(c, st, 4 + i, eae_conv_s2_ntiles(1, B, a.Hin, a.Win, cin[i]), (long long)B * (a.Hin * 2) * (a.Win * 2), train));
   }
   Deconv4Args d = Deconv4Args();
   d.src = src_bnrelu(c->u[2], c->coef_f[6]);
@@ -538,7 +604,10 @@ int run_decoder(eae_ctx* c, hipStream_t st, const float* z, int B, bool train, c
   d.x = target; d.x_hat = x_hat; d.g4 = want_grad ? c->g4 : nullptr; d.loss_part = (want_loss || want_grad) ? c->msepart : nullptr;
   d.gscale = gscale; d.B = B; d.Hin = H / 2; d.Win = W / 2;
   fold_consumer(c, d.fold, 6, (long long)B * (H / 2) * (W / 2), train);
-  RC(eae_launch_deconv4_loss(st, SRC_BNRELU, d));
+  {
+    ProfBracket pb(c, EAE_PROF_DECONV4_LOSS, st);
+    RC(eae_launch_deconv4_loss(st, SRC_BNRELU, d));
+  }
   return 0;
 }
 
@@ -568,7 +637,7 @@ int check_io(eae_ctx* c, const eae_step_io* io, bool need_grad) {
 int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_grad) {
   const int B = io->B;
   const bool train = io->train != 0;
-  c->fwd_ready = train; c->fwd_B = B; c->fwd_head = io->head; c->fwd_x = io->x;
+  c->fwd_ready = train; c->fwd_B = B; c->fwd_head = io->head; c->fwd_x = io->x; c->fwd_gen += 1;
   RC(ensure_packed(c, st));
   RC(prep_accumulators(c, st, train));
   RC(run_encoder(c, st, io->x, B, train));
@@ -603,79 +672,133 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
   return 0;
 }
 
+// Side work (weight gradients, their slice reductions, the head-gradient reduction) only feeds the optimizer, so it runs on the
+// engine's side streams beside the backward-data chain.  Every hand-over costs the chain one event record on the caller's
+// stream (~5 us of bubble each, tools/timeline.py), so the launches are QUEUED and handed over in groups: one record per group,
+// waited on by every side stream that receives a member.  Members go round-robin over the side streams (each stream has its own
+// split-K scratch: a weight gradient and its slice reduction stay on one stream).
+struct SideQueue {
+  eae_ctx* c;
+  hipStream_t main;
+  std::vector<std::function<int(hipStream_t, float*)>> items;
+  void push(std::function<int(hipStream_t, float*)> f) { items.push_back(std::move(f)); }
+  int flush() {
+    if (items.empty()) return 0;
+    int rc = 0;
+    if (!c->use_side) {
+      for (auto& f : items) if (!rc) rc = f(main, c->wscratch);
+      items.clear();
+      return rc;
+    }
+    const int ns = 1 + c->nx;
+    hipEvent_t ev = c->ev_fork[c->ev_i];
+    c->ev_i = (c->ev_i + 1) % eae_ctx::NEV;
+    EAE_HIP(hipEventRecord(ev, main));
+    const int used = (int)items.size() < ns ? (int)items.size() : ns;
+    for (int k = 0; k < used; ++k) {
+      const int sidx = (c->side_rr + k) % ns;
+      EAE_HIP(hipStreamWaitEvent(sidx == 0 ? c->side : c->sidex[sidx - 1], ev, 0));
+    }
+    for (auto& f : items) {
+      const int sidx = c->side_rr++ % ns;
+      if (!rc) rc = f(sidx == 0 ? c->side : c->sidex[sidx - 1], sidx == 0 ? c->wscratch : c->wscratchx[sidx - 1]);
+    }
+    items.clear();
+    return rc;
+  }
+};
+
 // part 0 = everything, 1 = classifier + decoder + dec.fc (gradient tensors 18..37), 2 = enc.fc + encoder (tensors 0..17)
 int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float* dz_ext = nullptr, int part = 0) {
   const int B = io->B, H = c->H, W = c->W;
   const bool head = io->head != 0;
-  hipStream_t ss;       // side streams: everything that only feeds the optimizer (weight gradients and their reductions)
-  float* scr = c->wscratch;
+  // Default: every weight gradient is handed over as soon as its inputs exist (9 records).  EAE_FORK_GROUPS=1 hands them over in
+  // 5 groups instead: measured SLOWER (0.596 vs 0.570 ms at B=512) -- the records saved (~5 us each) cost less than what two
+  // 12-wave weight-gradient kernels running back to back on the side streams take away from the backward-data chain.
+  static const bool fork_every = getenv("EAE_FORK_GROUPS") == nullptr;
+  const bool dp = part != 0 || c->dp_stream[0] != nullptr || c->dp_stream[1] != nullptr;
+  SideQueue sq{c, st, {}};
+  auto maybe_flush = [&]() -> int { return fork_every ? sq.flush() : 0; };
   c->side_rr = 0;
-  if (c->side_forked && part != 2) ss = c->side;      // forward_impl forked at this very position for the loss finalize
-  else RC(fork_side(c, st, &ss));
-  c->side_forked = false;
   if (part != 2) {
-  // ---- classifier weight gradients (partials written by the head kernel)
-  if (head) {
-    const int nb = eae_head_blocks(B);
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(c->head_stride / 4)), dim3(256), 0, ss, c->headpart, nb,
-                       (long)(c->head_stride / 4), c->G + c->poff[34], 1.0f);
-    EAE_LAUNCH_CHECK();
-  } else {
-    EAE_HIP(hipMemsetAsync(c->G + c->poff[34], 0, (size_t)(c->poff[38] - c->poff[34]) * 4, ss));
-  }
-  // ---- deconv4: weight gradient, then backward-data into u[2]'s BN+ReLU
-  c->side_rr = 1;                // this group stays on `side` (already forked here); the next group starts the round-robin at side #1
-  RC(eae_launch_edge_wgrad(ss, SRC3_NHWC4_BF16, c->g4, B, H, W, src_bnrelu(c->u[2], c->coef_f[6]), SRC_BNRELU, scr,
-                           c->wscratch_floats, c->G + c->poff[32]));
-  {
-    EdgeArgs a;
-    a.src3 = c->g4; a.B = B; a.H = H; a.W = W;
-    a.c = ConvArgs();
-    a.c.wpack = (const bf16_t*)(c->pack + c->pk_d4k); a.c.out = c->gu[2]; a.c.stat_part = c->stat;
-    a.c.yprev = c->u[2]; a.c.prev_coef = c->coef_f[6]; a.c.B = B;
-    RC(eae_launch_edge_conv(st, SRC3_NHWC4_BF16, EPI_MASK, a));
-    RC(bn_bwd_fin(c, st, 6, eae_edge_tiles(B, H, W), (long long)B * (H / 2) * (W / 2)));
-  }
-  // ---- deconv3, deconv2, deconv1 (i = 2, 1, 0)
-  const int dcin[3] = {256, 128, 64};
-  for (int i = 2; i >= 0; --i) {
-    const int cs = dcin[i], cb = dcin[i] / 2;         // deconv weight [cs][cb][3][3]
-    const int Hs = H >> (4 - i), Ws = W >> (4 - i);   // input (small) map of the deconv
-    WgradArgs w = WgradArgs();
-    w.small = (i == 0) ? src_raw(c->d0) : src_bnrelu(c->u[i - 1], c->coef_f[3 + i]);
-    w.big = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
-    w.B = B; w.Hs = Hs; w.Ws = Ws;
-    RC(fork_wgrad(c, st, &ss, &scr));       // needs coef_b[4+i] (BN-backward finalize of this layer's output)
-    RC(eae_launch_wgrad_s2(ss, w, cs, cb, i == 0 ? SRC_RAW : SRC_BNRELU, SRC_BNBWD, scr, c->wscratch_floats,
-                           c->G + c->poff[20 + 4 * i]));
-    ConvArgs a = ConvArgs();
-    a.src = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
-    a.wpack = (const bf16_t*)(c->pack + c->pk_p1[3 + i]);
-    a.B = B; a.Hin = Hs * 2; a.Win = Ws * 2;
-    if (i > 0) {
-      a.out = c->gu[i - 1]; a.stat_part = c->stat; a.yprev = c->u[i - 1]; a.prev_coef = c->coef_f[3 + i];
-      RC(eae_launch_conv_s2(a, cb, cs, SRC_BNBWD, EPI_MASK, st));
-      RC(bn_bwd_fin(c, st, 3 + i, eae_conv_s2_ntiles(0, B, a.Hin, a.Win), (long long)B * Hs * Ws));
+    // ---- first group: forward_impl forked `side` at this very position of the main stream for the loss finalize
+    hipStream_t ss;
+    if (c->side_forked) ss = c->side;
+    else RC(fork_side(c, st, &ss));
+    c->side_forked = false;
+    c->side_rr = 1;                // the first queued group starts the round-robin at side stream #1
+    // classifier weight gradients (partials written by the head kernel)
+    if (head) {
+      const int nb = eae_head_blocks(B);
+      hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(c->head_stride / 4)), dim3(256), 0, ss, c->headpart, nb,
+                         (long)(c->head_stride / 4), c->G + c->poff[34], 1.0f);
+      EAE_LAUNCH_CHECK();
     } else {
-      a.out = c->gd0;
-      RC(eae_launch_conv_s2(a, cb, cs, SRC_BNBWD, EPI_PLAIN, st));
+      EAE_HIP(hipMemsetAsync(c->G + c->poff[34], 0, (size_t)(c->poff[38] - c->poff[34]) * 4, ss));
     }
-  }
-  // ---- dec.fc: weight/bias gradient and dz
-  {
-    FcTnArgs t = FcTnArgs();
-    t.p = src_raw(c->gd0); t.q = src_f32(c->z); t.Bt = B; t.I = (int)c->K; t.J = c->L;
-    t.out = c->G + c->poff[18]; t.colsum = c->G + c->poff[19]; t.out_mode = 0; t.Pn = (int)c->Pn;
-    RC(fork_wgrad(c, st, &ss, &scr));       // needs gd0
-    RC(eae_launch_fc_tn(ss, t, SRC_RAW, SRC_F32));
-    FcNtArgs f = FcNtArgs();
-    f.a = src_raw(c->gd0); f.w = (const bf16_t*)(c->pack + c->pk_wd2);
-    f.M = B; f.N = c->L; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
-    const int ksplit = (int)(c->K / 128);
-    RC(eae_launch_fc_nt(st, f, SRC_RAW, FCE_PARTIAL, ksplit));
-    if (c->head_pending) { EAE_HIP(hipStreamWaitEvent(st, c->ev_head, 0)); c->head_pending = false; }
-    RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, nullptr, head ? c->dzc : nullptr, dz_ext, c->dz));
-  }
+    // ---- deconv4: weight gradient, then backward-data into u[2]'s BN+ReLU
+    RC(eae_launch_edge_wgrad(ss, SRC3_NHWC4_BF16, c->g4, B, H, W, src_bnrelu(c->u[2], c->coef_f[6]), SRC_BNRELU, c->wscratch,
+                             c->wscratch_floats, c->G + c->poff[32]));
+    {
+      EdgeArgs a;
+      a.src3 = c->g4; a.B = B; a.H = H; a.W = W;
+      a.c = ConvArgs();
+      a.c.wpack = (const bf16_t*)(c->pack + c->pk_d4k); a.c.out = c->gu[2]; a.c.stat_part = c->stat;
+      a.c.yprev = c->u[2]; a.c.prev_coef = c->coef_f[6]; a.c.B = B;
+      {
+        ProfBracket pb(c, EAE_PROF_DECONV4_BWD, st);
+        RC(eae_launch_edge_conv(st, SRC3_NHWC4_BF16, EPI_MASK, a));
+      }
+      RC(bn_bwd_fin(c, st, 6, eae_edge_tiles(B, H, W), (long long)B * (H / 2) * (W / 2)));
+    }
+    // ---- deconv3, deconv2, deconv1 (i = 2, 1, 0): weight gradients queued, handed over together before the last dgrad
+    const int dcin[3] = {256, 128, 64};
+    for (int i = 2; i >= 0; --i) {
+      const int cs = dcin[i], cb = dcin[i] / 2;         // deconv weight [cs][cb][3][3]
+      const int Hs = H >> (4 - i), Ws = W >> (4 - i);   // input (small) map of the deconv
+      sq.push([=](hipStream_t s2, float* scr) {          // needs coef_b[4+i] (BN-backward finalize of this layer's output)
+        WgradArgs w = WgradArgs();
+        w.small = (i == 0) ? src_raw(c->d0) : src_bnrelu(c->u[i - 1], c->coef_f[3 + i]);
+        w.big = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
+        w.B = B; w.Hs = Hs; w.Ws = Ws;
+        return eae_launch_wgrad_s2(s2, w, cs, cb, i == 0 ? SRC_RAW : SRC_BNRELU, SRC_BNBWD, scr, c->wscratch_floats, c->G + c->poff[20 + 4 * i],
+                                   prof_hook_for(c, i == 2 ? EAE_PROF_DECONV3_WGRAD : -1));
+      });
+      if (i == 0) RC(sq.flush()); else RC(maybe_flush());
+      ConvArgs a = ConvArgs();
+      a.src = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
+      a.wpack = (const bf16_t*)(c->pack + c->pk_p1[3 + i]);
+      a.B = B; a.Hin = Hs * 2; a.Win = Ws * 2;
+      if (i > 0) {
+        a.out = c->gu[i - 1]; a.stat_part = c->stat; a.yprev = c->u[i - 1]; a.prev_coef = c->coef_f[3 + i];
+        {
+          ProfBracket pb(c, i == 2 ? EAE_PROF_DECONV3_BWD : -1, st);
+          RC(eae_launch_conv_s2(a, cb, cs, SRC_BNBWD, EPI_MASK, st));
+        }
+        RC(bn_bwd_fin(c, st, 3 + i, eae_conv_s2_ntiles(0, B, a.Hin, a.Win), (long long)B * Hs * Ws));
+      } else {
+        a.out = c->gd0;
+        RC(eae_launch_conv_s2(a, cb, cs, SRC_BNBWD, EPI_PLAIN, st));
+      }
+    }
+    // ---- dec.fc: weight/bias gradient (queued: needs gd0) and dz
+    sq.push([=](hipStream_t s2, float*) {
+      FcTnArgs t = FcTnArgs();
+      t.p = src_raw(c->gd0); t.q = src_f32(c->z); t.Bt = B; t.I = (int)c->K; t.J = c->L;
+      t.out = c->G + c->poff[18]; t.colsum = c->G + c->poff[19]; t.out_mode = 0; t.Pn = (int)c->Pn;
+      return eae_launch_fc_tn(s2, t, SRC_RAW, SRC_F32);
+    });
+    RC(maybe_flush());
+    {
+      FcNtArgs f = FcNtArgs();
+      f.a = src_raw(c->gd0); f.w = (const bf16_t*)(c->pack + c->pk_wd2);
+      f.M = B; f.N = c->L; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
+      const int ksplit = (int)(c->K / 128);
+      RC(eae_launch_fc_nt(st, f, SRC_RAW, FCE_PARTIAL, ksplit));
+      if (c->head_pending) { EAE_HIP(hipStreamWaitEvent(st, c->ev_head, 0)); c->head_pending = false; }
+      RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, nullptr, head ? c->dzc : nullptr, dz_ext, c->dz));
+    }
+    if (dp) RC(sq.flush());        // the hand-off below covers gradient tensors 18..37 only
   }   // part != 2
   if (part == 1) return fold_side2(c);     // the caller may now all-reduce gradient tensors 18..37 behind the side stream
   if (part == 0 && c->dp_stream[0]) {      // same hand-off without splitting the call: see eae_dp_stream()
@@ -683,13 +806,15 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     EAE_HIP(hipEventRecord(c->ev_part[0], c->side));
     EAE_HIP(hipStreamWaitEvent(c->dp_stream[0], c->ev_part[0], 0));
   }
-  // ---- enc.fc: weight/bias gradient and backward-data into y[3]'s BN+ReLU
-  {
+  // ---- enc.fc: weight/bias gradient (queued with the dec.fc one: needs dz) and backward-data into y[3]'s BN+ReLU
+  sq.push([=](hipStream_t s2, float*) {
     FcTnArgs t = FcTnArgs();
     t.p = src_f32(c->dz); t.q = src_bnrelu(c->y[3], c->coef_f[3]); t.Bt = B; t.I = c->L; t.J = (int)c->K;
     t.out = c->G + c->poff[16]; t.colsum = c->G + c->poff[17]; t.out_mode = 1; t.Pn = (int)c->Pn;
-    RC(fork_wgrad(c, st, &ss, &scr));       // needs dz
-    RC(eae_launch_fc_tn(ss, t, SRC_F32, SRC_BNRELU));
+    return eae_launch_fc_tn(s2, t, SRC_F32, SRC_BNRELU);
+  });
+  RC(sq.flush());
+  {
     FcNtArgs f = FcNtArgs();
     f.a = src_f32(c->dz); f.w = (const bf16_t*)(c->pack + c->pk_we2);
     f.M = B; f.N = (int)c->K; f.K = c->L; f.klen = c->L;
@@ -698,34 +823,40 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     RC(eae_launch_fc_nt(st, f, SRC_F32, FCE_MASK, 1));
     RC(bn_bwd_fin(c, st, 3, ((B + 127) / 128) * (int)c->Pn, (long long)B * c->Pn));
   }
-  // ---- conv4, conv3, conv2 (i = 3, 2, 1): weight gradient + backward-data
+  // ---- conv4, conv3, conv2 (i = 3, 2, 1): weight gradient (queued; conv4 + conv3 go together, conv2 before the last dgrad so
+  //      that it runs beside it and beside conv1's weight gradient) + backward-data
   for (int i = 3; i >= 1; --i) {
     const int cs = ENC_C[i + 1], cb = ENC_C[i];       // conv weight [cs][cb][3][3]
     const int Hs = H >> (i + 1), Ws = W >> (i + 1);   // output (small) map of the conv
-    WgradArgs w = WgradArgs();
-    w.small = src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
-    w.big = src_bnrelu(c->y[i - 1], c->coef_f[i - 1]);
-    w.B = B; w.Hs = Hs; w.Ws = Ws;
-    RC(fork_wgrad(c, st, &ss, &scr));       // needs coef_b[i]
-    RC(eae_launch_wgrad_s2(ss, w, cs, cb, SRC_BNBWD, SRC_BNRELU, scr, c->wscratch_floats, c->G + c->poff[4 * i]));
+    sq.push([=](hipStream_t s2, float* scr) {            // needs coef_b[i]
+      WgradArgs w = WgradArgs();
+      w.small = src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
+      w.big = src_bnrelu(c->y[i - 1], c->coef_f[i - 1]);
+      w.B = B; w.Hs = Hs; w.Ws = Ws;
+      return eae_launch_wgrad_s2(s2, w, cs, cb, SRC_BNBWD, SRC_BNRELU, scr, c->wscratch_floats, c->G + c->poff[4 * i],
+                                 prof_hook_for(c, i == 1 ? EAE_PROF_CONV2_WGRAD : -1));
+    });
+    if (i != 3) RC(sq.flush()); else RC(maybe_flush());
     ConvArgs a = ConvArgs();
     a.src = src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
     a.wpack = (const bf16_t*)(c->pack + c->pk_p2[i - 1]);
     a.out = c->gy[i - 1]; a.stat_part = c->stat; a.yprev = c->y[i - 1]; a.prev_coef = c->coef_f[i - 1];
     a.B = B; a.Hin = Hs; a.Win = Ws;
-    RC(eae_launch_deconv_s2(a, cs, cb, SRC_BNBWD, EPI_MASK, st));
-    RC(bn_bwd_fin(c, st, i - 1, eae_conv_s2_ntiles(1, B, Hs, Ws), (long long)B * (Hs * 2) * (Ws * 2)));
+    {
+      ProfBracket pb(c, i == 1 ? EAE_PROF_CONV2_BWD : -1, st);
+      RC(eae_launch_deconv_s2(a, cs, cb, SRC_BNBWD, EPI_MASK, st));
+    }
+    RC(bn_bwd_fin(c, st, i - 1, eae_conv_s2_ntiles(1, B, Hs, Ws, cs), (long long)B * (Hs * 2) * (Ws * 2)));
     if (i == 2 && part == 0 && c->dp_stream[1]) {     // enc.fc, conv4 and conv3 weight gradients have been enqueued
       RC(fold_side2(c));
       EAE_HIP(hipEventRecord(c->ev_part[1], c->side));
       EAE_HIP(hipStreamWaitEvent(c->dp_stream[1], c->ev_part[1], 0));
     }
   }
-  // ---- conv1 weight gradient
   // ---- conv1 weight gradient: nothing is left for the main stream to do, so the last weight gradient runs there (no fork
   //      latency in the tail of the step) while the side streams drain
   RC(eae_launch_edge_wgrad(st, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, c->wscratch_main,
-                           512LL * 864, c->G + c->poff[0]));
+                           512LL * 864, c->G + c->poff[0], prof_hook_for(c, EAE_PROF_CONV1_WGRAD)));
   RC(join_side(c, st));
   // Biases in front of a BatchNorm have an identically zero gradient (the reference computes ~1e-9 rounding noise);
   // their slots in the gradient arena are zeroed once in eae_bind and never written.
@@ -741,15 +872,21 @@ extern "C" int eae_ae_forward(eae_ctx* c, void* stream, const eae_step_io* io) {
 
 // Backward of the most recent TRAIN-mode eae_ae_forward for externally supplied output gradients (the autograd path:
 // `loss.backward()` on a torch loss built from x_hat / logits / z, R.md:649-653).  Activations of that forward are still
-// resident in the workspace.  Any of dx_hat / dlogits / dz may be NULL (= zero).
-extern "C" int eae_ae_backward(eae_ctx* c, void* stream, const float* x_hat, const float* dx_hat, const float* dlogits, const float* dz) {
+// resident in the workspace; the INPUT batch is not (conv1's weight gradient reads it): the caller passes it again, together
+// with the generation id of the forward it differentiates.  Any of dlogits / dz may be NULL (= zero).
+extern "C" long long eae_forward_generation(eae_ctx* c) { return c ? c->fwd_gen : -1; }
+extern "C" int eae_ae_backward(eae_ctx* c, void* stream, long long generation, const float* x, const float* x_hat, const float* dx_hat,
+                               const float* dlogits, const float* dz) {
   if (!c || !c->G) return eae_set_error(EAE_ERR_STATE, "backward: no gradient arena bound");
   if (!c->fwd_ready) return eae_set_error(EAE_ERR_STATE, "backward: no train-mode forward is resident (call eae_ae_forward with train=1 first)");
-  if (!x_hat || !dx_hat) return eae_set_error(EAE_ERR_ARG, "backward: x_hat and dx_hat are required");
+  if (generation != c->fwd_gen)
+    return eae_set_error(EAE_ERR_STATE, "backward: a later forward has replaced the activations of the forward being differentiated "
+                                        "(one backward per forward, in order)");
+  if (!x || !x_hat || !dx_hat) return eae_set_error(EAE_ERR_ARG, "backward: x, x_hat and dx_hat are required");
   hipStream_t st = (hipStream_t)stream;
   const int B = c->fwd_B;
   eae_step_io io = eae_step_io();
-  io.x = c->fwd_x; io.B = B; io.train = 1; io.head = (dlogits != nullptr) ? 1 : 0;
+  io.x = x; io.B = B; io.train = 1; io.head = (dlogits != nullptr) ? 1 : 0;
   RC(eae_launch_sigmoid_bwd(st, x_hat, dx_hat, c->g4, c->msepart, B, c->H, c->W));
   const int nblk = (int)(((long long)B * c->H * c->W + 255) / 256);
   RC(eae_launch_loss_finalize(st, c->msepart, nblk, nullptr, 0, 0.f, 1.0, B, c->G + c->poff[33], nullptr, nullptr));
@@ -918,7 +1055,7 @@ extern "C" int eae_op_conv_s2(void* stream, int kind, eae_src src, int cin, int 
   if (kind == 0) return eae_launch_conv_s2(a, cin, cout, src.mode, epilogue, (hipStream_t)stream);
   return eae_launch_deconv_s2(a, cin, cout, src.mode, epilogue, (hipStream_t)stream);
 }
-extern "C" int eae_op_conv_s2_ntiles(int kind, int B, int Hin, int Win) { return eae_conv_s2_ntiles(kind, B, Hin, Win); }
+extern "C" int eae_op_conv_s2_ntiles(int kind, int cin, int B, int Hin, int Win) { return eae_conv_s2_ntiles(kind, B, Hin, Win, cin); }
 
 extern "C" int eae_op_edge_conv(void* stream, int src3_kind, const void* src3, int B, int H, int W, const void* wpack, const float* bias,
                                 void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef) {

@@ -1,6 +1,7 @@
 // Host-side dispatch of the unified stride-2 conv / transposed-conv implicit-GEMM kernel (eae_igemm.hip.h).
 #include "eae_internal.h"
 #include "eae_igemm.hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -30,8 +31,17 @@ int conv_geo(const ConvArgs& a, hipStream_t st) {
   return eae_set_error(-2, "conv_s2: unsupported spatial size (output must be 4x4, 8x8 or a multiple of 8x16)");
 }
 
+// The 64->32 transposed kind on 16x8-position tiles launches B*2 workgroups of 3 per CU at 64x64 images: 1024 workgroups on 768
+// slots at B=512, i.e. TWO rounds of workgroups (deconv3 forward 22 us, conv2 backward-data 44 us for 50 / 100 MB).  16x4 tiles
+// (half the accumulators: 4 per CU) make it 2048 half-size workgroups on 1024 slots -- measured SLOWER (28.1 vs 22.4 us stand-alone,
+// 0.569 vs 0.562 ms per step): the round count is not what bounds this kernel.  Kept reachable with EAE_DECONV64_TH4=1.
+static bool deconv64_th4() { static const bool v = getenv("EAE_DECONV64_TH4") != nullptr; return v; }
+
 template <int CIN, int COUT, int BN, int SRC, int EPI>
 int deconv_geo(const ConvArgs& a, hipStream_t st) {
+  if constexpr (CIN == 64) {
+    if (a.Win % 16 == 0 && a.Hin % 4 == 0 && deconv64_th4()) return launch<KIND_DECONV, CIN, COUT, BN, 16, 4, 1, SRC, EPI>(a, st);
+  }
   if (a.Win % 16 == 0 && a.Hin % 8 == 0) return launch<KIND_DECONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st);
   if (a.Win == 8 && a.Hin == 8) return launch<KIND_DECONV, CIN, COUT, BN, 8, 8, 1, SRC, EPI>(a, st);
   if (a.Win == 4 && a.Hin == 4) return launch<KIND_DECONV, CIN, COUT, BN, 4, 4, 4, SRC, EPI>(a, st);
@@ -76,7 +86,8 @@ int eae_launch_deconv_s2(const ConvArgs& a, int cin, int cout, int src, int epi,
 }
 
 // number of per-workgroup statistics partials (= grid.x) for a given shape
-int eae_conv_s2_ntiles(int kind, int B, int Hin, int Win) {
+int eae_conv_s2_ntiles(int kind, int B, int Hin, int Win, int cin) {
+  if (kind == 1 && cin == 64 && Win % 16 == 0 && Hin % 4 == 0 && deconv64_th4()) return B * (Hin / 4) * (Win / 16);
   if (kind == 0) {
     int Hp = Hin / 2, Wp = Win / 2;
     if (Wp % 16 == 0 && Hp % 8 == 0) return B * (Hp / 8) * (Wp / 16);

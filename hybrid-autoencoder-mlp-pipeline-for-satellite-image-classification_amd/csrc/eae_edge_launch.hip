@@ -26,7 +26,7 @@ int eae_edge_tiles(int B, int H, int W) { return B * (H / 2 / E_TH) * (W / 2 / E
 
 // dw [32][3][3][3] = reduce over blocks of the per-block partials. scratch must hold nblocks*864 floats.
 int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B, int H, int W, const SrcDesc& side, int smode,
-                          float* scratch, long long scratch_floats, float* dw) {
+                          float* scratch, long long scratch_floats, float* dw, const EaeProfHook* hook) {
   if (int rc = check_edge_shape(B, H, W)) return rc;
   EdgeWgradArgs a;
   a.src3 = src3; a.B = B; a.H = H; a.W = W; a.side = side; a.part = scratch;
@@ -35,7 +35,7 @@ int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B
   a.tiles_per_block = (a.ntiles + nblocks - 1) / nblocks;
   nblocks = (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
   if ((long long)nblocks * 864 > scratch_floats) return eae_set_error(-2, "edge_wgrad: scratch too small");
-#define CASE(S, M) if (src3_kind == S && smode == M) { hipLaunchKernelGGL((edge_wgrad_kernel<S, M>), dim3(nblocks), dim3(256), 0, st, a); EAE_LAUNCH_CHECK(); goto reduce; }
+#define CASE(S, M) if (src3_kind == S && smode == M) { if (hook) hook->begin(hook->user, st); hipLaunchKernelGGL((edge_wgrad_kernel<S, M>), dim3(nblocks), dim3(256), 0, st, a); if (hook) hook->end(hook->user, st); EAE_LAUNCH_CHECK(); goto reduce; }
   CASE(SRC3_NCHW_F32, SRC_BNBWD)
   CASE(SRC3_NHWC4_BF16, SRC_BNRELU)
   CASE(SRC3_NCHW_F32, SRC_RAW)

@@ -195,10 +195,11 @@ struct Geo {
 // waves per SIMD the register allocation aims at (= workgroups per CU): the 32<->64-channel layers launch 1024 workgroups
 // at B=512, which only fit the 256 CUs in ONE round at 4 per CU (128 VGPRs, <= 40 KB LDS)
 // (the 64->32 transposed kind keeps 4 phases x 4 m-tiles of accumulators: 3 per CU is what fits without spilling)
-constexpr int ig_occ(int kind, int cin, int cout) { return cin > 64 ? 1 : (cin * cout > 2048 ? 2 : (kind == 0 ? 4 : 3)); }
+// A 64-position tile of the transposed kind (2 m-tiles x 4 phases of accumulators per wave) fits the budget of 4 per CU as well.
+constexpr int ig_occ(int kind, int cin, int cout, int P = 128) { return cin > 64 ? 1 : (cin * cout > 2048 ? 2 : ((kind == 0 || P == 64) ? 4 : 3)); }
 
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
-__global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT)) void igemm_s2_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void igemm_s2_kernel(ConvArgs a) {
   using G = Geo<KIND, TW, TH, NI>;
   static_assert(G::P == 64 || G::P == 128, "tile must hold 64 or 128 positions");
   static_assert(CIN % 32 == 0 && COUT % BN == 0 && (BN == 32 || BN == 64), "shape");
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT)) void igemm_s2_kernel(
   constexpr int NPA = (NPIX * 4 + 255) / 256;       // 16-byte patch pieces per thread
   constexpr int TS = BN + 8;
   constexpr bool ROWSWEEP = (TW == 16 && NI == 1);      // m-tile == one tile row: sweep the patch rows (see the MFMA loop)
-  constexpr int PFB = ig_occ(KIND, CIN, COUT) >= 4 ? 1 : 2;   // pixel-fragment register buffers (double buffering costs 4*MT VGPRs)
+  constexpr int PFB = ig_occ(KIND, CIN, COUT, G::P) >= 4 ? 1 : 2;   // pixel-fragment register buffers (double buffering costs 4*MT VGPRs)
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
   bf16_t* patch = smem;                             // [NPIX][PIX_STRIDE]; reused as the output tile [P][TS] + reduction scratch
 

@@ -9,7 +9,7 @@ int eae_set_error(int code, const char* msg);   // records the message for eae_l
 struct ConvArgs;
 int eae_launch_conv_s2(const ConvArgs& a, int cin, int cout, int src, int epi, hipStream_t st);
 int eae_launch_deconv_s2(const ConvArgs& a, int cin, int cout, int src, int epi, hipStream_t st);
-int eae_conv_s2_ntiles(int kind, int B, int Hin, int Win);
+int eae_conv_s2_ntiles(int kind, int B, int Hin, int Win, int cin = 0);   // statistics partials per channel = workgroups along grid.x
 
 #define EAE_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return eae_set_error(-3, hipGetErrorString(e__)); } while (0)
 
@@ -30,15 +30,17 @@ inline hipError_t eae_smem_attr(const void* func, size_t bytes) {
 
 #include "eae_misc.h"
 #include "eae_head.h"
+// optional bracket around the MAIN kernel of a launcher that enqueues more than one (weight gradient + slice reduction)
+struct EaeProfHook { void (*begin)(void* user, hipStream_t st); void (*end)(void* user, hipStream_t st); void* user; };
 struct SrcDesc;
 struct EdgeArgs; struct Deconv4Args; struct WgradArgs; struct FcNtArgs; struct FcTnArgs;
 int eae_launch_edge_conv(hipStream_t st, int src3_kind, int epi, const EdgeArgs& a);
 int eae_edge_tiles(int B, int H, int W);
 int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B, int H, int W, const SrcDesc& side, int smode,
-                          float* scratch, long long scratch_floats, float* dw);
+                          float* scratch, long long scratch_floats, float* dw, const EaeProfHook* hook = nullptr);
 int eae_launch_deconv4_loss(hipStream_t st, int smode, const Deconv4Args& a);
 int eae_launch_wgrad_s2(hipStream_t st, const WgradArgs& a, int cs, int cb, int smode, int bmode, float* scratch,
-                        long long scratch_floats, float* dw);
+                        long long scratch_floats, float* dw, const EaeProfHook* hook = nullptr);
 int eae_launch_fc_nt(hipStream_t st, const FcNtArgs& a, int amode, int epi, int ksplit);
 int eae_launch_fc_reduce(hipStream_t st, const float* part, int nsl, int M, int N, const float* bias, const float* addend,
                          const float* addend2, float* out);

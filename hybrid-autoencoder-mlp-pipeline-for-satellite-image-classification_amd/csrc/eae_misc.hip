@@ -99,6 +99,45 @@ __global__ EAE_NO_PK __launch_bounds__(256) void bn_bwd_finalize_kernel(const fl
   }
 }
 
+// SyncBN form of the backward finalize, split at the point where the replicas exchange their sums (dp.py):
+//   reduce: part -> sums[2][C] in fp64 (this replica's sum g, sum g*xhat) and its LOCAL dgamma / dbeta (the gradient exchange sums them)
+//   coef  : A, B, C from the GLOBAL sums (after the all-reduce) and the global element count
+__global__ EAE_NO_PK __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ part, int ntiles, int C, double* __restrict__ sums,
+                                                             float* dgamma, float* dbeta) {
+  __shared__ double red[512];
+  const int ch = blockIdx.x;
+  double a, b;
+  reduce_partials_ch(part, ntiles, C, ch, red, a, b);
+  if (threadIdx.x == 0) {
+    sums[ch] = a; sums[C + ch] = b;
+    if (dbeta) dbeta[ch] = (float)a;
+    if (dgamma) dgamma[ch] = (float)b;
+  }
+}
+__global__ EAE_NO_PK void bn_bwd_coef_kernel(const double* __restrict__ sums, int C, float count, const float* __restrict__ gamma,
+                                             const float* __restrict__ coef_fwd, float* __restrict__ coef_bwd) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= C) return;
+  const float db = (float)sums[ch], dg = (float)sums[C + ch];
+  const float mean = coef_fwd[2 * C + ch], invstd = coef_fwd[3 * C + ch];
+  const float A = gamma[ch] * invstd;
+  const float Bc = -A * invstd * dg / count;
+  coef_bwd[ch] = A;
+  coef_bwd[C + ch] = Bc;
+  coef_bwd[2 * C + ch] = -A * db / count - Bc * mean;
+}
+int eae_launch_bn_bwd_reduce(hipStream_t st, const float* part, int ntiles, int C, double* sums, float* dgamma, float* dbeta) {
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C), dim3(256), 0, st, part, ntiles, C, sums, dgamma, dbeta);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+int eae_launch_bn_bwd_coef(hipStream_t st, const double* sums, int C, long long count, const float* gamma, const float* coef_fwd,
+                           float* coef_bwd) {
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sums, C, (float)count, gamma, coef_fwd, coef_bwd);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+
 int eae_launch_bn_finalize(hipStream_t st, const float* part, int ntiles, int C, long long count, const float* gamma,
                            const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, part, ntiles, C, (float)count, gamma, beta, rm,

@@ -6,6 +6,15 @@ arena (5.26 MB) is all-reduced in a few large buckets and divided by the world s
 rank (identical updates keep the replicas in sync).  BatchNorm uses per-rank batch statistics (DDP semantics).
 
 The collective goes through ``torch.distributed`` so that the same code runs on RCCL (GPU) and gloo (CPU tests).
+
+Default exchange: ONE all-reduce of the whole arena after the backward (``EAE_DP_OVERLAP=0`` semantics).  ``EAE_DP_OVERLAP=1``
+hands the decoder-side bucket to RCCL while the encoder half of the backward is still running; it stays
+opt-in until it has run on more than one rank: the repo's co-residency finding (wrong low lanes of ``v_pk_*_f32 op_sel:``
+forms beside MFMA kernels) rests on black-box A/B runs, and although RCCL's gfx950 code contains no such instruction
+(``build.scan_packed_fp32_rccl``: 325 packed-FP32 instructions, 0 with ``op_sel:``) that is evidence, not validation.
+
+``sync_bn=True`` sums the BatchNorm batch statistics over the replicas (forward: the fixed-point accumulators, exact; backward:
+the fp64 sums), so that R ranks x B/R images reproduce one rank x B images; the default keeps per-rank statistics.
 """
 from __future__ import annotations
 
@@ -28,8 +37,45 @@ def bucket_bounds(offsets, total, n_buckets=3):
     return [(cuts[1], total), (cuts[0], cuts[1]), (0, cuts[0])]
 
 
+class SyncBatchNorm:
+    """Hooks the engine's BatchNorm statistics into an all-reduce over `process_group` (eae_set_sync_bn, include/eae.h)."""
+
+    def __init__(self, engine, process_group=None):
+        import ctypes as C
+        from ._lib import SYNC_FN, check
+        self.eng, self.pg = engine, process_group
+        self.world = dist.get_world_size(process_group)
+        n = int(engine.lib.eae_sync_bn_acc_elems(engine.ctx))
+        self.acc = torch.zeros(n, dtype=torch.int64, device=engine.device)
+        self.sums = torch.zeros(7 * 2 * 256, dtype=torch.float64, device=engine.device)
+        self.error = None
+        self._cb = SYNC_FN(self._exchange)       # keep the ctypes thunk alive as long as the engine may call it
+        with torch.cuda.device(engine.device):
+            check(engine.lib.eae_set_sync_bn(engine.ctx, self.world, C.cast(self._cb, C.c_void_p), None,
+                                             C.c_void_p(self.acc.data_ptr()), C.c_void_p(self.sums.data_ptr())))
+        engine._sync_bn = self
+
+    def _exchange(self, user, kind, off, count, stream):
+        try:
+            t = (self.acc if kind == 0 else self.sums)[off: off + count]
+            dev = self.eng.device
+            s = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
+            with torch.cuda.stream(s):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+            return 0
+        except Exception as e:      # never let an exception cross the C boundary: the engine reports EAE_ERR_STATE, we re-raise
+            self.error = e
+            return -1
+
+    def close(self):
+        from ._lib import check
+        with torch.cuda.device(self.eng.device):
+            check(self.eng.lib.eae_set_sync_bn(self.eng.ctx, 1, None, None, None, None))
+        self.eng.params_changed()
+
+
 class DataParallelTrainer:
-    def __init__(self, engine, process_group=None, n_buckets=3):
+    def __init__(self, engine, process_group=None, n_buckets=3, sync_bn=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised (launch one process per GPU with torch.distributed.run)")
         self.eng = engine
@@ -38,6 +84,7 @@ class DataParallelTrainer:
         self.rank = dist.get_rank(process_group)
         self.buckets = bucket_bounds(engine.poff, engine.poff[38], n_buckets)
         self._comm = None                      # high-priority stream the collectives are enqueued from (GPU engines only)
+        self.sync_bn = SyncBatchNorm(engine, process_group) if (sync_bn and self.world > 1 and hasattr(engine, "ctx")) else None
 
     def broadcast_parameters(self, src=0):
         """Identical initial replicas: parameters, BatchNorm running stats and Adam state from rank `src`."""
@@ -66,10 +113,9 @@ class DataParallelTrainer:
             self.allreduce_gradients()
             eng.adam_step(lr)
             return
-        if os.environ.get("EAE_DP_OVERLAP", "1") == "0":     # collectives strictly after the backward
+        if os.environ.get("EAE_DP_OVERLAP", "0") != "1":     # default: ONE collective strictly after the backward
             eng.grad_step(x, labels, alpha, head=head)
-            for lo, hi in ((eng.poff[18], eng.poff[38]), (0, eng.poff[18])):
-                dist.all_reduce(eng.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+            dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM, group=self.pg)
             eng.adam_step(lr, grad_scale=1.0 / self.world)
             return
         cut = eng.poff[18]
@@ -107,3 +153,50 @@ class DataParallelTrainer:
             dist.all_reduce(eng.grads[0:cut], op=dist.ReduceOp.SUM, group=self.pg)
             h1.wait()
         eng.adam_step(lr, grad_scale=1.0 / self.world)
+
+
+class DPAEStepper:
+    """Data-parallel stepper for train.fit_autoencoder (same interface as train.AEStepper): every rank feeds ITS shard of each
+    batch; gradients are averaged every step, the epoch scalars (sample-weighted loss sums, counts) are all-reduced ONCE per
+    epoch phase, so every rank sees the reference's global epoch means (R.md:656-660, 679-683) and takes the same
+    early-stopping decisions."""
+
+    def __init__(self, model, alpha, lr, head=True, max_batch=None, process_group=None, sync_bn=False):
+        from .engine import engine_for
+        self.model, self.alpha, self.lr, self.head = model, float(alpha), float(lr), head
+        self.eng = engine_for(model, max_batch=max_batch)
+        self.eng.reset_optimizer()
+        self.device = self.eng.device
+        self.pg = process_group
+        self.trainer = DataParallelTrainer(self.eng, process_group, sync_bn=sync_bn)
+        self.trainer.broadcast_parameters()
+
+    def begin(self):
+        self.eng.reset_loss()
+
+    def train_step(self, imgs, labels):
+        self.trainer.train_step(imgs, labels, self.alpha, self.lr, head=self.head)
+        if self.trainer.sync_bn is not None and self.trainer.sync_bn.error is not None:
+            raise self.trainer.sync_bn.error
+
+    def eval_step(self, imgs, labels):
+        self.eng.forward(imgs, labels=labels, train=False, head=self.head, alpha=self.alpha, want=(), accum=True)
+
+    def end(self):
+        acc = self.eng.loss_accum.clone()
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.pg)
+        a = acc.tolist()
+        n = max(a[3], 1.0)
+        return a[0] / n, int(a[3])
+
+
+def fit_autoencoder_dp(train_loader, val_loader, alpha, lr, process_group=None, sync_bn=False, model=None, latent_dim=64,
+                       num_classes=10, device="cuda", **kw):
+    """train.fit_autoencoder (R.md:619-697) with one process per GPU: `train_loader` / `val_loader` yield THIS rank's shard."""
+    from .modules import SupervisedAutoencoder
+    from .train import fit_autoencoder, _first_batch_size
+    if model is None:
+        model = SupervisedAutoencoder(latent_dim=latent_dim, num_classes=num_classes).to(device)
+    st = DPAEStepper(model, alpha, lr, head=kw.pop("head", True), process_group=process_group, sync_bn=sync_bn,
+                     max_batch=max(_first_batch_size(train_loader), _first_batch_size(val_loader)))
+    return fit_autoencoder(train_loader, val_loader, alpha, lr, model=model, stepper=st, **kw)

@@ -29,6 +29,18 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _on_device(fn):
+    """Run an engine method with the engine's device current: the C context allocates its workspace and streams on the current
+    device and every launch goes to that device's current stream (a model on cuda:1 with current device 0)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **k)
+    return wrapper
+
+
 def _require_gpu(device):
     if device.type != "cuda" or not torch.cuda.is_available():
         raise RuntimeError("the autoencoder engine runs on a HIP device only (model.to('cuda')); there is no CPU path")
@@ -95,12 +107,23 @@ class AEEngine:
             self.params[self.poff[g]: self.poff[g] + c] = 1.0
         self._adopt()
         h = C.c_void_p()
-        check(self.lib.eae_create(C.byref(self.cfg), C.byref(h)))
-        self.ctx = h
-        check(self.lib.eae_bind(self.ctx, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
-                                _ptr(self.bn_running), _ptr(self.bn_nbt)))
-        self._finalizer = weakref.finalize(self, _destroy, self.lib, self.ctx)
-        root.register_load_state_dict_post_hook(lambda m, k: self.params_changed())
+        with torch.cuda.device(self.device):
+            check(self.lib.eae_create(C.byref(self.cfg), C.byref(h)))
+            self.ctx = h
+            check(self.lib.eae_bind(self.ctx, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
+                                    _ptr(self.bn_running), _ptr(self.bn_nbt)))
+        self._finalizer = weakref.finalize(self, _destroy, self.lib, self.ctx, self.device)
+        # one hook per module, reaching whichever engine currently serves it (a rebuilt engine must not keep the old one alive)
+        if not getattr(root, "_eae_hooked", False):
+            rref = weakref.ref(root)
+
+            def _hook(module, incompatible_keys):
+                r = rref()
+                eng = _ENGINES.get(r) if r is not None else None
+                if eng is not None:
+                    eng.params_changed()
+            root.register_load_state_dict_post_hook(_hook)
+            root._eae_hooked = True
 
     # ------------------------------------------------------------------ arena management
     def _adopt(self):
@@ -137,6 +160,10 @@ class AEEngine:
     def params_changed(self):
         check(self.lib.eae_params_changed(self.ctx))
 
+    def generation(self):
+        """Id of the most recent forward (eae_ae_backward only differentiates the resident one)."""
+        return int(self.lib.eae_forward_generation(self.ctx))
+
     def expose_grads(self):
         """Make ``p.grad`` of every parameter a view of the gradient arena (after a fused grad step)."""
         for p, i in self._slots:
@@ -167,6 +194,7 @@ class AEEngine:
                        _ptr(self.loss_accum) if accum else None, _ptr(self.loss_last))
         return io, (x, labels)
 
+    @_on_device
     def forward(self, x, labels=None, train=False, head=True, alpha=1.0, want=("x_hat", "logits", "z"), accum=False):
         b = x.shape[0]
         x_hat = torch.empty((b, 3, self.size, self.size), dtype=torch.float32, device=self.device) if "x_hat" in want else None
@@ -176,19 +204,23 @@ class AEEngine:
         check(self.lib.eae_ae_forward(self.ctx, _stream(), C.byref(io)))
         return x_hat, logits, z
 
+    @_on_device
     def grad_step(self, x, labels, alpha, head=True, x_hat=None):
         io, keep = self._io(x, labels, True, head, alpha, x_hat)
         check(self.lib.eae_ae_grad_step(self.ctx, _stream(), C.byref(io)))
 
+    @_on_device
     def adam_step(self, lr, weight_decay=0.0, grad_scale=1.0):
         check(self.lib.eae_adam_step_scaled(self.ctx, _stream(), float(lr), float(weight_decay), float(grad_scale)))
 
+    @_on_device
     def grad_step_begin(self, x, labels, alpha, head=True):
         """forward + loss + backward of classifier / decoder / dec.fc: gradient tensors 18..37 complete behind the side stream"""
         io, keep = self._io(x, labels, True, head, alpha)
         self._keep = keep
         check(self.lib.eae_ae_grad_step_begin(self.ctx, _stream(), C.byref(io)))
 
+    @_on_device
     def grad_step_end(self):
         check(self.lib.eae_ae_grad_step_end(self.ctx, _stream()))
         self._keep = None
@@ -204,11 +236,13 @@ class AEEngine:
         h = self.lib.eae_dp_stream(self.ctx, int(which))
         return torch.cuda.ExternalStream(h, device=self.device) if h else None
 
+    @_on_device
     def train_step(self, x, labels, alpha, lr, head=True, x_hat=None):
         """One iteration of the reference's batch loop (R.md:646-657); the loss is accumulated on the device."""
         io, keep = self._io(x, labels, True, head, alpha, x_hat)
         check(self.lib.eae_ae_train_step(self.ctx, _stream(), C.byref(io), float(lr)))
 
+    @_on_device
     def encoder(self, x, train=False):
         b = x.shape[0]
         z = torch.empty((b, self.latent), dtype=torch.float32, device=self.device)
@@ -216,6 +250,7 @@ class AEEngine:
         check(self.lib.eae_encoder_forward(self.ctx, _stream(), _ptr(keep[0]), b, int(train), _ptr(z)))
         return z
 
+    @_on_device
     def decoder(self, z, train=False):
         if z.device != self.device or z.dtype != torch.float32 or z.dim() != 2 or z.shape[1] != self.latent:
             raise RuntimeError(f"expected float32 latent [B,{self.latent}] on {self.device}")
@@ -227,6 +262,7 @@ class AEEngine:
         check(self.lib.eae_decoder_forward(self.ctx, _stream(), _ptr(z), b, int(train), _ptr(x_hat)))
         return x_hat
 
+    @_on_device
     def reset_optimizer(self):
         self.adam_m.zero_()
         self.adam_v.zero_()
@@ -242,9 +278,13 @@ class AEEngine:
         return a[0] / n, a[1] / n, a[2] / n, int(a[3]), int(a[4])
 
 
-def _destroy(lib, ctx):
+def _destroy(lib, ctx, device=None):
     try:
-        lib.eae_destroy(ctx)
+        if device is not None:
+            with torch.cuda.device(device):
+                lib.eae_destroy(ctx)
+        else:
+            lib.eae_destroy(ctx)
     except Exception:
         pass
 
@@ -273,10 +313,19 @@ def engine_for(module, max_batch=None):
     dev = next(root.parameters()).device
     _require_gpu(dev)
     want_mb = max_batch or getattr(root, "_eae_max_batch", 512)
-    if eng is not None and (not eng.attached() or eng.device != dev or eng.max_batch < want_mb):
+    old = None
+    if eng is not None and (not eng.attached() or eng.device != dev):
         eng = None     # parameters were moved / re-created: rebuild the arenas from the module's current tensors
+    elif eng is not None and eng.max_batch < want_mb:
+        old, eng = eng, None     # same parameters, bigger workspace: the optimizer state moves to the new engine
     if eng is None:
         eng = AEEngine(root, max_batch=want_mb)
+        if old is not None:
+            with torch.no_grad():
+                eng.adam_m.copy_(old.adam_m)
+                eng.adam_v.copy_(old.adam_v)
+                eng.loss_accum.copy_(old.loss_accum)
+            check(eng.lib.eae_set_adam_step(eng.ctx, old.lib.eae_get_adam_step(old.ctx)))
         _ENGINES[root] = eng
     return eng
 
@@ -288,9 +337,11 @@ class _AEFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eng, x, *params):
+        x = x.contiguous()          # the backward reads the batch again (conv1 weight gradient): keep OUR copy alive, not the caller's
         x_hat, logits, z = eng.forward(x, train=True, head=True)
         ctx.eng = eng
-        ctx.save_for_backward(x_hat)
+        ctx.gen = eng.generation()
+        ctx.save_for_backward(x, x_hat)
         ctx.nparams = len(params)
         ctx.need = [p.requires_grad for p in params]
         return x_hat, logits, z
@@ -298,19 +349,17 @@ class _AEFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx_hat, dlogits, dz):
         eng = ctx.eng
-        (x_hat,) = ctx.saved_tensors
-        dev = eng.device
+        x, x_hat = ctx.saved_tensors
 
-        def prep(t, like_shape):
-            if t is None:
-                return None
-            return t.to(dtype=torch.float32).contiguous()
+        def prep(t):
+            return None if t is None else t.to(dtype=torch.float32).contiguous()
 
-        dx_hat = prep(dx_hat, None)
+        dx_hat = prep(dx_hat)
         if dx_hat is None:
             dx_hat = torch.zeros_like(x_hat)
-        dlogits, dz = prep(dlogits, None), prep(dz, None)
-        check(eng.lib.eae_ae_backward(eng.ctx, _stream(), _ptr(x_hat), _ptr(dx_hat), _ptr(dlogits), _ptr(dz)))
+        dlogits, dz = prep(dlogits), prep(dz)
+        with torch.cuda.device(eng.device):
+            check(eng.lib.eae_ae_backward(eng.ctx, _stream(), ctx.gen, _ptr(x), _ptr(x_hat), _ptr(dx_hat), _ptr(dlogits), _ptr(dz)))
         grads = []
         for (p, i), need in zip(eng._slots, ctx.need):
             grads.append(eng.grads[eng.poff[i]: eng.poff[i] + p.numel()].view(p.shape).clone() if need else None)

@@ -2,8 +2,8 @@
 (R.md:2415-2425), the loss curves (R.md:2460-2469), the confusion matrix (R.md:3188-3190) and the per-class report the
 notebook prints with sklearn's `classification_report(..., digits=4)` (R.md:3216-3237).
 
-Numbers are computed with NumPy only (sklearn / matplotlib are not needed to get them); the `plot_*` helpers draw the same
-figures as the notebook when matplotlib is importable and write them to a file instead of `plt.show()`.
+Numbers only, computed with NumPy (sklearn is not needed to get them).  Drawing the figures is out of scope (SURVEY.md section 2:
+plotting).
 """
 import json
 
@@ -94,50 +94,3 @@ def classification_report(labels, preds, digits=4):
     lines.append(row.format("macro avg", *m["macro"], m["total"], w=width, d=digits))
     lines.append(row.format("weighted avg", *m["weighted"], m["total"], w=width, d=digits))
     return "\n".join(lines) + "\n"
-
-
-def _plt():
-    try:
-        import matplotlib
-        matplotlib.use("Agg")
-        import matplotlib.pyplot as plt
-        return plt
-    except Exception as e:      # plotting is optional; the numbers above never need it
-        raise RuntimeError("matplotlib is required for the plot_* helpers") from e
-
-
-def plot_loss_heatmap(results, alpha_values, lr_values, path):
-    """Figure of R.md:2427-2437, saved to `path`."""
-    plt = _plt()
-    hm = loss_heatmap(results, alpha_values, lr_values)
-    plt.figure(figsize=(10, 6))
-    plt.imshow(hm, cmap="viridis", aspect="auto")
-    plt.colorbar(label="Validation Loss")
-    plt.xticks(range(len(lr_values)), lr_values, rotation=45)
-    plt.yticks(range(len(alpha_values)), alpha_values)
-    plt.xlabel("Learning Rate"); plt.ylabel("Alpha"); plt.title("Validation Loss Heatmap")
-    plt.tight_layout(); plt.savefig(path); plt.close()
-    return hm
-
-
-def plot_loss_curves(train_losses, val_losses, title, path):
-    """Figure of R.md:2460-2469 (AE) / the MLP curves, saved to `path`."""
-    plt = _plt()
-    plt.figure(figsize=(10, 5))
-    plt.plot(train_losses, label="Train Loss"); plt.plot(val_losses, label="Validation Loss")
-    plt.title(title); plt.xlabel("Epoch"); plt.ylabel("Loss"); plt.legend(); plt.grid(True, alpha=0.3)
-    plt.savefig(path); plt.close()
-
-
-def plot_confusion_matrix(labels, preds, path, title="Confusion Matrix – Best MLP"):
-    """Figure of R.md:3190-3196, saved to `path`."""
-    plt = _plt()
-    cm = confusion_matrix(labels, preds)
-    plt.figure(figsize=(8, 8))
-    plt.imshow(cm, cmap="Blues")
-    for i in range(cm.shape[0]):
-        for j in range(cm.shape[1]):
-            plt.text(j, i, format(int(cm[i, j]), "d"), ha="center", va="center", color="white" if cm[i, j] > cm.max() / 2 else "black")
-    plt.xlabel("Predicted label"); plt.ylabel("True label"); plt.title(title); plt.colorbar()
-    plt.savefig(path); plt.close()
-    return cm

@@ -77,9 +77,13 @@ typedef struct eae_step_io {
 /* x_hat, logits, z = model(x) (R.md:647 / 673), plus the loss terms when io->x target / labels are given. */
 int eae_ae_forward(eae_ctx* ctx, void* stream, const eae_step_io* io);
 /* loss.backward() for a torch-side loss (R.md:649-653): backward of the most recent train-mode eae_ae_forward given the
- * gradients of its outputs (fp32; dx_hat [B,3,H,W], dlogits [B,C] or NULL, dz [B,L] or NULL); x_hat = that forward's output.
+ * gradients of its outputs (fp32; dx_hat [B,3,H,W], dlogits [B,C] or NULL, dz [B,L] or NULL).  x = that forward's input batch
+ * (conv1's weight gradient reads it again: the engine keeps no pointer to caller memory across calls), x_hat = its output,
+ * generation = eae_forward_generation() read right after that forward: EAE_ERR_STATE if any forward ran since.
  * Gradients of all 38 tensors land in the grad arena (biases in front of a BatchNorm: exact zeros). */
-int eae_ae_backward(eae_ctx* ctx, void* stream, const float* x_hat, const float* dx_hat, const float* dlogits, const float* dz);
+long long eae_forward_generation(eae_ctx* ctx);
+int eae_ae_backward(eae_ctx* ctx, void* stream, long long generation, const float* x, const float* x_hat, const float* dx_hat,
+                    const float* dlogits, const float* dz);
 /* zero_grad + forward + loss + backward (R.md:646-653): gradients of all 38 tensors land in the grad arena. */
 int eae_ae_grad_step(eae_ctx* ctx, void* stream, const eae_step_io* io);
 /* optimizer.step() of torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) over the bound arenas (R.md:624, 654). */
@@ -98,6 +102,15 @@ void* eae_side_stream(eae_ctx* ctx);
  * disabled. */
 void* eae_dp_stream(eae_ctx* ctx, int which);
 int eae_adam_step_scaled(eae_ctx* ctx, void* stream, float lr, float weight_decay, float grad_scale);
+/* Synchronized BatchNorm across data-parallel replicas (new work; SURVEY.md 8e: R ranks x B/R with SyncBN == 1 rank x B).
+ * In train mode the engine calls `fn` once per BatchNorm layer in the forward (kind 0: `count` int64 fixed-point accumulators
+ * starting at element `elem_offset` of acc_i64) and once per layer in the backward (kind 1: `count` fp64 sums at element
+ * `elem_offset` of sums_f64): the hook all-reduces (SUM) that range over the replicas, enqueued on `stream`, and returns 0.
+ * acc_i64: caller-owned device buffer of eae_sync_bn_acc_elems() int64 (zero-initialised); sums_f64: 7*2*256 fp64.
+ * world <= 1 or fn NULL switches it off (per-replica statistics, the default: DDP semantics). */
+typedef int (*eae_sync_fn)(void* user, int kind, long long elem_offset, long long count, void* stream);
+long long eae_sync_bn_acc_elems(eae_ctx* ctx);
+int eae_set_sync_bn(eae_ctx* ctx, int world, eae_sync_fn fn, void* user, void* acc_i64, void* sums_f64);
 /* eae_ae_grad_step + eae_adam_step: one iteration of the reference's batch loop (R.md:642-658). */
 int eae_ae_train_step(eae_ctx* ctx, void* stream, const eae_step_io* io, float lr);
 /* Encoder alone in the current mode (extract_features, R.md:2504: z = encoder(imgs)). */
@@ -105,10 +118,22 @@ int eae_encoder_forward(eae_ctx* ctx, void* stream, const float* x, int B, int t
 /* Decoder alone (Decoder.forward, R.md:386-389). */
 int eae_decoder_forward(eae_ctx* ctx, void* stream, const float* z, int B, int train, float* x_hat);
 
-/* In-situ timing of the dominant kernel (enc.conv2 forward, conv_s2_kernel<32,64,...>) inside real train steps:
- * HIP events are recorded on the launch stream around that launch for up to 64 steps; eae_profile_read synchronises them
- * and returns the summed kernel time and the number of launches measured (bench.py's `roofline` object). */
-int eae_profile_enable(eae_ctx* ctx, int on);
+/* In-situ timing of ONE launch site inside real train steps (bench.py's `roofline` object): HIP events are recorded around that
+ * launch, on the stream it goes to, for up to 64 steps; eae_profile_read2 synchronises them and returns the summed bracket time,
+ * the summed time of an EMPTY bracket recorded right behind each timed one (what the two event records cost by themselves) and
+ * the number of launches measured.  site 0 switches the timing off.  Kernel behind each site (rocprofv3 name): */
+#define EAE_PROF_OFF 0
+#define EAE_PROF_CONV2_FWD 1      /* igemm_s2_kernel<0, 32, 64, 64, 16, 8, 1, 1, 0>   enc.conv2 forward */
+#define EAE_PROF_CONV2_BWD 2      /* igemm_s2_kernel<1, 64, 32, 32, 16, 8, 1, 2, 1>   enc.conv2 backward-data */
+#define EAE_PROF_DECONV3_BWD 3    /* igemm_s2_kernel<0, 32, 64, 64, 16, 8, 1, 2, 1>   dec.deconv3 backward-data */
+#define EAE_PROF_CONV2_WGRAD 4    /* wgrad_s2_kernel<64, 32, 16, 8, 1, 2, 1>          enc.conv2 weight gradient */
+#define EAE_PROF_DECONV3_WGRAD 5  /* wgrad_s2_kernel<64, 32, 16, 8, 1, 1, 2>          dec.deconv3 weight gradient */
+#define EAE_PROF_DECONV4_LOSS 6   /* deconv4_loss_kernel<1>                           dec.deconv4 + sigmoid + MSE + gradient */
+#define EAE_PROF_CONV1_WGRAD 7    /* edge_wgrad_kernel<0, 2>                          enc.conv1 weight gradient */
+#define EAE_PROF_DECONV4_BWD 8    /* edge_conv_kernel<1, 1>                           dec.deconv4 backward-data */
+#define EAE_PROF_DECONV3_FWD 9    /* igemm_s2_kernel<1, 64, 32, 32, 16, 8, 1, 1, 0>   dec.deconv3 forward */
+#define EAE_PROF_NSITES 10
+int eae_profile_enable(eae_ctx* ctx, int site);
 /* diagnostic: copy an internal fp32 buffer (0 z, 1 dz, 2 dz_head, 3 head partials, 4 CE partials) to dst (device) */
 int eae_debug_copy(eae_ctx* ctx, int which, float* dst, long long n);
 int eae_profile_read(eae_ctx* ctx, double* total_ms, long long* count);
@@ -131,7 +156,8 @@ typedef struct eae_src {
  * 1: ReLU mask of (yprev, prev_coef) + BN-backward partials; 2: plain store. */
 int eae_op_conv_s2(void* stream, int kind, eae_src src, int cin, int cout, int B, int Hin, int Win, const void* wpack,
                    const float* bias, void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef);
-int eae_op_conv_s2_ntiles(int kind, int B, int Hin, int Win);
+/* number of statistics partials per channel (= workgroups) eae_op_conv_s2 writes for this shape */
+int eae_op_conv_s2_ntiles(int kind, int cin, int B, int Hin, int Win);
 /* first / last layer kernels: src3_kind 0 = fp32 NCHW [B,3,H,W], 1 = bf16 NHWC4 [B,H,W,4]; out [B,H/2,W/2,32] */
 int eae_op_edge_conv(void* stream, int src3_kind, const void* src3, int B, int H, int W, const void* wpack32x64 /* k = tap*4 + c */,
                      const float* bias, void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef);

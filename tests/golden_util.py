@@ -45,3 +45,12 @@ def tensor_digest(a, stride=97):
     """(sum, l2, strided sample) digest of a big tensor for compact fixtures."""
     f = np.asarray(a, dtype=np.float64).ravel()
     return np.array([f.sum(), np.sqrt((f * f).sum())], np.float64), np.asarray(a, np.float32).ravel()[::stride].copy()
+
+
+def is_prebn_bias(name):
+    """Conv / deconv biases in front of a BatchNorm: analytically zero gradient (the engine writes exact zeros, the reference
+    computes ~1e-9 rounding noise that Adam turns into a +-lr random walk: DESIGN.md section 5)."""
+    parts = name.split(".")
+    return name.endswith(".bias") and (
+        name.startswith("enc.encoder.") and parts[2] in ("0", "3", "6", "9")
+        or name.startswith("dec.decoder.") and parts[2] in ("1", "4", "7"))

@@ -165,6 +165,52 @@ def test_fit_loops_end_to_end(tmp_path):
     assert abs((preds == labels).mean() - r2["test_acc"]) < 1e-6
 
 
+def test_grid_search_drivers_on_the_engine(tmp_path):
+    """N2 (R.md:599-729, 2611-2732): the grid drivers with their DEFAULT fit functions, i.e. on the HIP engine: every
+    configuration gets a fresh model and optimizer state, the global best is tracked, AE_GLOBAL_BEST.pt /
+    validation_losses.json / MLP_GLOBAL_BEST.pt are written with the reference's keys and load back into fresh modules."""
+    import json
+    import eae_amd
+    torch.manual_seed(0)
+    rng = np.random.default_rng(1)
+    n = 96
+    y = rng.integers(0, 10, n)
+    base = rng.random((10, 3, 64, 64)).astype(np.float32)
+    x = np.clip(base[y] + 0.05 * rng.standard_normal((n, 3, 64, 64)).astype(np.float32), 0, 1)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y.astype(np.int64))
+
+    def loader(lo, hi, bs=32):
+        return [(xt[i:min(i + bs, hi)], yt[i:min(i + bs, hi)]) for i in range(lo, hi, bs)]
+
+    tr, va, te = loader(0, 64), loader(64, 80), loader(80, 96)
+    logs = []
+    g = eae_amd.grid_search_autoencoder(tr, va, alpha_values=(20, 35), lr_values=(1e-3, 5e-3), num_epochs=2, patience=15,
+                                        out_dir=str(tmp_path / "models_best"), verbose=True, log=logs.append)
+    assert set(g["results"].keys()) == {(20, 1e-3), (20, 5e-3), (35, 1e-3), (35, 5e-3)}
+    assert all(np.isfinite(v) for v in g["results"].values())
+    assert g["best_val_loss"] == min(g["results"].values()) and (g["best_alpha"], g["best_lr"]) == min(g["results"], key=g["results"].get)
+    js = json.load(open(tmp_path / "models_best" / "validation_losses.json"))
+    assert set(js.keys()) == {f"alpha={a}, lr={lr}" for a in (20, 35) for lr in (1e-3, 5e-3)}
+    assert any(line.startswith("[AE α=35 LR=0.005] Epoch 2 | TrainLoss=") for line in logs)
+    best_ae = eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=10).to("cuda")
+    best_ae.load_state_dict(torch.load(g["best_path"], weights_only=True))          # R.md:2594-2595
+    for p_ in best_ae.enc.parameters():
+        p_.requires_grad = False
+    best_ae.enc.eval()
+    feats = [eae_amd.extract_features(l, best_ae.enc) for l in (tr, va, te)]
+
+    def dl(X, Y, bs=64):
+        return [(X[i:i + bs], Y[i:i + bs]) for i in range(0, len(X), bs)]
+
+    gm = eae_amd.grid_search_mlp(dl(*feats[0]), dl(*feats[1]), dl(*feats[2]), lr_values=(1e-3, 1e-2), num_epochs=4,
+                                 out_dir=str(tmp_path / "mlp_best"), verbose=False)
+    assert gm["best_lr"] in (1e-3, 1e-2) and 0.0 <= gm["test_acc"] <= 1.0 and len(gm["curves"]["val_acc"]) == 4
+    clf = eae_amd.MLP(input_dim=64, num_classes=10).to("cuda")
+    clf.load_state_dict(torch.load(gm["best_path"], weights_only=True))             # R.md:3172-3173
+    preds, labels = eae_amd.evaluate(clf, dl(*feats[2]))
+    assert preds.shape == labels.shape == (16,)
+
+
 def test_mlp_autograd_drop_in_loop(golden):
     """The reference's MLP loop shape (R.md:2641-2646) with torch CE + torch.optim.Adam(weight_decay=1e-4) on the shell."""
     import torch.nn as nn

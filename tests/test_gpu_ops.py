@@ -51,7 +51,7 @@ def test_conv_s2_raw_fwd(lib, B, H):
     buf, p1, p2 = _pack(lib, w)
     xd = G.to_nhwc_bf16(x)
     out = torch.empty((B, H // 2, H // 2, 64), dtype=torch.bfloat16, device=G.dev())
-    nt = lib.eae_op_conv_s2_ntiles(0, B, H, H)
+    nt = lib.eae_op_conv_s2_ntiles(0, 32, B, H, H)
     part = torch.zeros((2, 64, nt), dtype=torch.float32, device=G.dev())
     bd = G.f32(b)
     check(lib.eae_op_conv_s2(G.stream(), 0, G.src(0, xd), 32, 64, B, H, H, G.ptr(p1), G.ptr(bd), G.ptr(out), G.ptr(part), 0, None, None))
@@ -75,7 +75,7 @@ def test_deconv_s2_raw_fwd(lib, B, H):
     buf, p1, p2 = _pack(lib, w)
     xd = G.to_nhwc_bf16(x)
     out = torch.empty((B, 2 * H, 2 * H, 32), dtype=torch.bfloat16, device=G.dev())
-    nt = lib.eae_op_conv_s2_ntiles(1, B, H, H)
+    nt = lib.eae_op_conv_s2_ntiles(1, 64, B, H, H)
     part = torch.zeros((2, 32, nt), dtype=torch.float32, device=G.dev())
     bd = G.f32(b)
     check(lib.eae_op_conv_s2(G.stream(), 1, G.src(0, xd), 64, 32, B, H, H, G.ptr(p2), G.ptr(bd), G.ptr(out), G.ptr(part), 0, None, None))

@@ -106,7 +106,7 @@ def test_igemm_instantiation(lib, kind, cin, cout, hin, smode, epi, B):
     bias = rng.standard_normal(cout).astype(np.float32) if epi == 0 else None
     bd = G.f32(bias) if bias is not None else None
     out = torch.zeros((B, hout, hout, cout), dtype=torch.bfloat16, device=G.dev())
-    nt = lib.eae_op_conv_s2_ntiles(kind, B, hin, hin)
+    nt = lib.eae_op_conv_s2_ntiles(kind, cin, B, hin, hin)
     part = torch.zeros((2, cout, nt), dtype=torch.float32, device=G.dev())
     yprev_d = pcoef_d = None
     if epi == 1:

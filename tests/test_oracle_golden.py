@@ -162,6 +162,53 @@ def test_ae_adam_trajectory(golden, tag, head):
             assert np.mean(err < 1e-3) > 0.98, (name, err.max())
 
 
+def test_ae_epoch_accounting(golden):
+    """R.md:642-684 driven by the reference's classes (tools/make_golden.py --round2): per-batch losses of one training epoch
+    (64, 64, 48) with Adam, the sample-weighted epoch mean, then the eval-mode validation epoch (64, 56)."""
+    g = golden("ae_epoch.npz")
+    p = ae_state_np()
+    st = O.new_adam_state()
+    alpha, lr = float(g["alpha"]), float(g["lr"])
+    tot, n = 0.0, 0
+    for i, b in enumerate(g["train_batches"]):
+        x, y = gu.make_images(int(b), int(g["train_seed0"]) + i)
+        loss, l_r, l_c, *_ = O.ae_train_step(p, st, x, y, alpha, lr)
+        # Adam's sign-like first steps amplify fp32 rounding noise from step to step (same effect as in test_ae_adam_trajectory)
+        rt = (5e-4, 1e-3, 3e-3)[i]
+        assert abs(loss - g["train_losses"][i]) <= rt * g["train_losses"][i], (i, loss)
+        assert abs(l_r - g["train_mse"][i]) <= rt * g["train_mse"][i] and abs(l_c - g["train_ce"][i]) <= 2 * rt * g["train_ce"][i]
+        tot += loss * int(b); n += int(b)
+    assert n == int(g["n_train"]) and abs(tot / n - g["train_epoch_loss"]) <= 1e-3 * g["train_epoch_loss"]
+    tot, n, correct = 0.0, 0, 0
+    for i, b in enumerate(g["val_batches"]):
+        x, y = gu.make_images(int(b), int(g["val_seed0"]) + i)
+        out = O.ae_forward(p, x, train=False)
+        loss, l_r, l_c = O.ae_loss(out, x, y, alpha)
+        assert abs(loss - g["val_losses"][i]) <= 5e-3 * g["val_losses"][i], (i, loss, g["val_losses"][i])
+        tot += loss * int(b); n += int(b); correct += int((out["logits"].argmax(1) == y).sum())
+    assert n == int(g["n_val"]) and abs(tot / n - g["val_epoch_loss"]) <= 5e-3 * g["val_epoch_loss"]
+    assert abs(correct - int(g["val_correct"])) <= 1
+
+
+def test_ae_one_adam_step(golden):
+    """The first Adam step moves every weight by -lr*sign(g) (bias-corrected m / sqrt(v) = g/|g|): elementwise check of the
+    gradient signs and the optimizer against the reference's parameters after one step."""
+    g = golden("ae_adam1_joint_b8.npz")
+    p = ae_state_np()
+    st = O.new_adam_state()
+    x, y = gu.make_images(8, int(g["seed"]))
+    loss, *_ = O.ae_train_step(p, st, x, y, float(g["alpha"]), float(g["lr"]))
+    assert abs(loss - g["loss"]) <= 2e-4 * g["loss"]
+    for k in g.files:
+        if not (k.startswith("final/") and k.endswith("/sample")):
+            continue
+        name = k[6:-7]
+        if "running" in name or "num_batches" in name or gu.is_prebn_bias(name):
+            continue
+        _, s = gu.tensor_digest(p[name])
+        assert np.mean(np.abs(s - g[k]) < 1e-4) > 0.97, (name, np.abs(s - g[k]).max())
+
+
 def test_mlp_forward_backward(golden):
     g = golden("mlp_fwd_bwd_b64.npz")
     p = mlp_state_np()

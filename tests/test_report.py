@@ -66,9 +66,3 @@ def test_heatmap_and_best_config(tmp_path):
     assert hm.shape == (2, 2) and hm[1, 1] == 0.5397 and hm[0, 0] == pytest.approx(0.201)
     res2 = dict(res); res2["alpha=20, lr=0.001"] = 0.1
     assert R.best_config(res2) == (20.0, 0.001, 0.1)
-    pytest.importorskip("matplotlib")
-    R.plot_loss_heatmap(loaded, alphas, lrs, str(tmp_path / "hm.png"))
-    R.plot_loss_curves([1.0, 0.5], [1.1, 0.7], "Loss Curves", str(tmp_path / "c.png"))
-    y, p = _case(3, 200, 4)
-    R.plot_confusion_matrix(y, p, str(tmp_path / "cm.png"))
-    assert (tmp_path / "hm.png").stat().st_size > 0 and (tmp_path / "cm.png").stat().st_size > 0

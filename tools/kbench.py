@@ -51,7 +51,7 @@ for (cin, cout, h) in ((32, 64, 32), (64, 128, 16), (128, 256, 8)):
             ci, co, hin = cout, cin, h // 2
             x = bf((B, hin, hin, ci)); out = bf((B, hin * 2, hin * 2, co))
         w = bf((co, 9, ci)); bias = torch.randn(co, device=dev)
-        nt = lib.eae_op_conv_s2_ntiles(kind, B, hin, hin)
+        nt = lib.eae_op_conv_s2_ntiles(kind, ci, B, hin, hin)
         part = torch.zeros((nt, 2, co), device=dev)
         cf = coef(4, ci)
         s = G.src(0, x) if (kind == 1 and ci == 256) else G.src(1, x, None, cf)

@@ -24,7 +24,7 @@ for (kind, ci, co, hin) in ((0, 32, 64, 32), (0, 64, 128, 16), (0, 128, 256, 8),
     ho = hin // 2 if kind == 0 else hin * 2
     out = torch.empty((B, ho, ho, co), device=dev, dtype=torch.bfloat16)
     w = (torch.randn((co, 9, ci), device=dev) * 0.1).to(torch.bfloat16); bias = torch.randn(co, device=dev)
-    nt = lib.eae_op_conv_s2_ntiles(kind, B, hin, hin)
+    nt = lib.eae_op_conv_s2_ntiles(kind, ci, B, hin, hin)
     part = torch.zeros((nt, 2, co), device=dev)
     cf = torch.randn((4, ci), device=dev)
     for blk in (0, nt - 1):

@@ -47,10 +47,92 @@ def digest_sd(sd, prefix, store):
         store[f"{prefix}/{k}/sample"] = s
 
 
+def gen_round2(ref):
+    """Fixtures added in round 2 (`python tools/make_golden.py --round2` writes only these):
+      ae_epoch.npz        one training epoch (batches 64, 64, 48) + one validation epoch (64, 56) driven line by line as
+                          R.md:642-684: per-batch losses, the sample-weighted epoch means, eval-mode loss terms
+      ae_adam1_joint_b8.npz  parameters after ONE Adam step (the first step moves every weight by -lr*sign(g): an elementwise
+                          check of gradient signs + the optimizer kernel)"""
+    SAE = ref["SupervisedAutoencoder"]
+
+    def build_ae(latent=64):
+        torch.manual_seed(gu.AE_SEED)
+        m = SAE(latent_dim=latent, num_classes=10)
+        load_np(m, gu.perturb_bn(sd_np(m)))
+        return m
+
+    alpha, lr = 35.0, 5e-3
+    # ---- epoch accounting (R.md:638-684)
+    m = build_ae()
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    mse_fn, ce_fn = nn.MSELoss(), nn.CrossEntropyLoss()
+    st = {"alpha": np.float32(alpha), "lr": np.float32(lr), "train_batches": np.array([64, 64, 48]), "val_batches": np.array([64, 56]),
+          "train_seed0": np.int64(600), "val_seed0": np.int64(700)}
+    m.train()
+    train_loss, n_train = 0.0, 0
+    tl, tm, tc = [], [], []
+    for i, b in enumerate((64, 64, 48)):
+        x, y = gu.make_images(b, 600 + i)
+        imgs, labels = torch.from_numpy(x), torch.from_numpy(y)
+        opt.zero_grad()
+        x_hat, logits, _ = m(imgs)
+        loss_recon = mse_fn(x_hat, imgs)
+        loss_class = ce_fn(logits, labels)
+        loss = alpha * loss_recon + loss_class
+        loss.backward()
+        opt.step()
+        bs = imgs.size(0)
+        train_loss += loss.item() * bs
+        n_train += bs
+        tl.append(loss.item()); tm.append(loss_recon.item()); tc.append(loss_class.item())
+    train_loss /= n_train
+    st.update(train_losses=np.array(tl, np.float32), train_mse=np.array(tm, np.float32), train_ce=np.array(tc, np.float32),
+              train_epoch_loss=np.float32(train_loss), n_train=np.int64(n_train))
+    m.eval()
+    val_loss, n_val, vl, vm, vc, correct = 0.0, 0, [], [], [], 0
+    with torch.no_grad():
+        for i, b in enumerate((64, 56)):
+            x, y = gu.make_images(b, 700 + i)
+            imgs, labels = torch.from_numpy(x), torch.from_numpy(y)
+            x_hat, logits, _ = m(imgs)
+            loss_recon = mse_fn(x_hat, imgs)
+            loss_class = ce_fn(logits, labels)
+            loss = alpha * loss_recon + loss_class
+            bs = imgs.size(0)
+            val_loss += loss.item() * bs
+            n_val += bs
+            vl.append(loss.item()); vm.append(loss_recon.item()); vc.append(loss_class.item())
+            correct += int((logits.argmax(1) == labels).sum())
+    val_loss /= n_val
+    st.update(val_losses=np.array(vl, np.float32), val_mse=np.array(vm, np.float32), val_ce=np.array(vc, np.float32),
+              val_epoch_loss=np.float32(val_loss), n_val=np.int64(n_val), val_correct=np.int64(correct))
+    np.savez_compressed(os.path.join(OUT, "ae_epoch.npz"), **st)
+
+    # ---- one Adam step
+    m = build_ae()
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    x, y = gu.make_images(8, 100)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    opt.zero_grad()
+    xh, lg, _ = m(xt)
+    loss = alpha * mse_fn(xh, xt) + ce_fn(lg, yt)
+    loss.backward()
+    opt.step()
+    st = {"alpha": np.float32(alpha), "lr": np.float32(lr), "seed": np.int64(100), "loss": np.float32(loss.item())}
+    digest_sd(sd_np(m), "final", st)
+    np.savez_compressed(os.path.join(OUT, "ae_adam1_joint_b8.npz"), **st)
+    for f in ("ae_epoch.npz", "ae_adam1_joint_b8.npz"):
+        print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1e6:.2f} MB")
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
+    if "--round2" in sys.argv:
+        gen_round2(ref)
+        return
     SAE, MLP, Encoder, Decoder = ref["SupervisedAutoencoder"], ref["MLP"], ref["Encoder"], ref["Decoder"]
 
     # ---------------- init pin: same torch seed -> same default init
@@ -240,6 +322,7 @@ def main():
         loader.append((torch.from_numpy(x), torch.from_numpy(y)))
     X, Y = ref["extract_features"](loader, m.enc)
     np.savez_compressed(os.path.join(OUT, "extract_features.npz"), X=X.numpy(), y=Y.numpy())
+    gen_round2(ref)
     print("fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1e6:.2f} MB")

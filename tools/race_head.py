@@ -45,7 +45,7 @@ ho = hin // 2 if kind == 0 else hin * 2
 x = (torch.randn((B, hin, hin, ci), device=dev) * 0.5).to(torch.bfloat16)
 out = torch.empty((B, ho, ho, co), device=dev, dtype=torch.bfloat16)
 w = (torch.randn((co, 9, ci), device=dev) * 0.1).to(torch.bfloat16); bias = torch.randn(co, device=dev)
-nt = lib.eae_op_conv_s2_ntiles(kind, B, hin, hin)
+nt = lib.eae_op_conv_s2_ntiles(kind, ci, B, hin, hin)
 part = torch.zeros((2, co, nt), device=dev)
 cf = torch.randn((4, ci), device=dev)
 yprev = (torch.randn((B, ho, ho, co), device=dev)).to(torch.bfloat16); pcoef = torch.randn((4, co), device=dev)
