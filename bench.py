@@ -188,6 +188,8 @@ def main():
     loss = float(eng.loss_last[0].item())
     if not np.isfinite(loss):
         raise SystemExit("non-finite loss in the timed region")
+    if eng.gate_timeouts():
+        raise SystemExit("a side-stream gate timed out in the timed region (results invalid)")
 
     if rank == 0:
         total_images = args.batch * world * args.steps

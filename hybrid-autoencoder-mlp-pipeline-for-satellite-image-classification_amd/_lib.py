@@ -36,6 +36,7 @@ _PROTOS = {
     "eae_create": (C.c_int, [C.POINTER(EaeConfig), C.POINTER(vp)]),
     "eae_destroy": (C.c_int, [vp]),
     "eae_bind": (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
+    "eae_gate_timeouts": (C.c_longlong, [vp]),
     "eae_params_changed": (C.c_int, [vp]),
     "eae_set_adam_step": (C.c_int, [vp, C.c_longlong]),
     "eae_get_adam_step": (C.c_longlong, [vp]),

@@ -104,8 +104,18 @@ struct eae_ctx {
   void* sync_user = nullptr;
   double* sync_sums = nullptr;     // caller-owned device buffer [7][2][256] fp64
   bool fold_fwd = true;
-  bool side_forked = false;        // `side` already waits for the current position of the main stream (no kernel enqueued on main since)
   int side_rr = 0;
+  // Hand-overs to the side streams (sq_* below): queued launches, the progress value their group waits for, the value the next
+  // kernel of the caller's stream has to publish, and the device words: [0] progress of the caller's stream, [1 + k] work done
+  // by side stream k, [8] gate time-out report.
+  struct SideItem { std::function<int(hipStream_t, float*)> fn; int pin; };
+  std::vector<SideItem> sq_items;
+  unsigned sig_seq = 0, sq_wait = 0, pending_sig = 0;
+  bool sq_forked = false;          // the queued group has been released (sq_fork): commit it behind the next kernel of the caller's stream
+  unsigned* sigwords = nullptr;
+  unsigned side_done_seq[1 + MAXX] = {};
+  unsigned side_used = 0;          // bit k: side stream k received work since the last join
+  bool use_gates = true;           // device-side gates instead of event records on the caller's stream (EAE_FORK_EVENTS=1: events)
   hipStream_t own_main = nullptr;  // capture is not permitted on the legacy default stream: graphs run here, bracketed by events
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   static constexpr int NEV = 16;
@@ -220,7 +230,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   size_t o_mse = carve(std::max((size_t)eae_edge_tiles((int)Bm, c->H, c->W), (size_t)((Bm * c->H * c->W + 255) / 256)) * 4 * 4);
   const long long hb = eae_head_blocks((int)Bm);
   c->head_stride = r4(128LL * c->L) + 128 + r4(128LL * c->C) + r4(c->C);
-  size_t o_ce = carve(hb * 2 * 4), o_head = carve(hb * c->head_stride * 4), o_loss = carve(64 * 4), o_dyn = carve(64);
+  size_t o_ce = carve(hb * 2 * 4), o_head = carve(hb * c->head_stride * 4), o_loss = carve(64 * 4), o_dyn = carve(64), o_sig = carve(64);
   // ---- pack arena
   size_t poffb = 0;
   auto pcarve = [&](size_t bytes) { size_t o = poffb; poffb += (bytes + 255) & ~(size_t)255; return o; };
@@ -260,12 +270,15 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->msepart = (float*)(b + o_mse); c->cepart = (float*)(b + o_ce); c->headpart = (float*)(b + o_head); c->lossbuf = (float*)(b + o_loss);
   c->pack = b + o_pack; c->descs_dev = (PackDesc*)(b + o_desc);
   c->dyn = (float*)(b + o_dyn);
+  c->sigwords = (unsigned*)(b + o_sig);
+  c->use_gates = getenv("EAE_FORK_EVENTS") == nullptr;
   // hipGraph replay is opt-in (EAE_GRAPH=1): on ROCm 7.2 the replayed graph ran its two branches one after the other
   // (0.80 ms/step) while the eager two-stream launch sequence overlaps them (0.71 ms/step)
   c->use_graph = getenv("EAE_GRAPH") != nullptr && getenv("EAE_NO_GRAPH") == nullptr;
   e = hipMemcpy(c->descs_dev, descs.data(), descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(c->g4, 0, Bm * (size_t)c->H * c->W * 4 * 2);
   if (e == hipSuccess) e = hipMemset(c->acc_base, 0, c->acc_bytes);
+  if (e == hipSuccess) e = hipMemset(c->sigwords, 0, 64);
   c->acc_clean = true;
   c->fold_fwd = getenv("EAE_NO_FOLD_FWD") == nullptr;
   if (e != hipSuccess) { hipFree(c->ws); delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
@@ -382,6 +395,15 @@ extern "C" int eae_set_sync_bn(eae_ctx* c, int world, eae_sync_fn fn, void* user
   c->sync_world = world; c->sync_fn = fn; c->sync_user = user; c->sync_sums = static_cast<double*>(sums_f64);
   return 0;
 }
+// Diagnostic (synchronises the device): 0, or the progress value a gate kernel gave up waiting for after its bounded spin
+// (include/eae.h); the step in which that happened produced wrong gradients.
+extern "C" long long eae_gate_timeouts(eae_ctx* c) {
+  if (!c) return -1;
+  unsigned v = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(&v, c->sigwords + 8, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (long long)v;
+}
 extern "C" int eae_params_changed(eae_ctx* c) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->packed = false; c->fwd_ready = false; return 0; }
 extern "C" int eae_set_adam_step(eae_ctx* c, long long s) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->adam_step = s; return 0; }
 extern "C" long long eae_get_adam_step(eae_ctx* c) { return c ? c->adam_step : -1; }
@@ -422,15 +444,73 @@ struct ProfBracket {
   }
 };
 
-// fork: work enqueued on the returned stream starts after everything enqueued so far on `st`
-int fork_side(eae_ctx* c, hipStream_t st, hipStream_t* out) {
-  if (!c->use_side) { *out = st; return 0; }
-  hipEvent_t ev = c->ev_fork[c->ev_i];
-  c->ev_i = (c->ev_i + 1) % eae_ctx::NEV;
-  EAE_HIP(hipEventRecord(ev, st));
-  EAE_HIP(hipStreamWaitEvent(c->side, ev, 0));
-  *out = c->side;
-  return 0;
+// ---------------------------------------------------------------------------------------------------------------------
+// Hand-overs to the side streams.  Side work (the classification head, the loss bookkeeping, weight gradients and their slice
+// reductions) only feeds the optimizer, so it runs on engine-owned streams beside the dependency chain of the caller's stream.
+// Round 1 ordered every hand-over with an event record on the caller's stream: ~5 us of bubble each, 9-10 per step
+// (tools/timeline.py).  Now the order is kept on the DEVICE:
+//   sq_push   queue a launch (optionally pinned to side stream 0, whose order the head -> loss bookkeeping chain needs);
+//   sq_fork   the queued group may start once the caller's stream has completed everything enqueued so far: it gets the next
+//             progress value, which the NEXT kernel enqueued on the caller's stream publishes when it starts (take_sig);
+//   sq_commit called right after that kernel has been enqueued: a one-wave gate kernel that polls the progress word goes to
+//             every side stream that receives a member, then the members (round robin; each stream has its own split-K scratch).
+// The gate is always enqueued AFTER the kernel that releases it, so streams that share a hardware queue cannot dead-lock, and its
+// spin is bounded (eae_gate_timeouts).  EAE_FORK_EVENTS=1, and hipGraph capture, use event records instead.
+// ---------------------------------------------------------------------------------------------------------------------
+bool gates_now(const eae_ctx* c) { return c->use_gates && !c->capturing; }
+hipStream_t side_stream(eae_ctx* c, int k) { return k == 0 ? c->side : c->sidex[k - 1]; }
+void sq_push(eae_ctx* c, std::function<int(hipStream_t, float*)> f, int pin = -1) { c->sq_items.push_back({std::move(f), pin}); }
+void sq_fork(eae_ctx* c) {
+  if (c->sq_items.empty() || c->sq_forked) return;
+  c->sq_forked = true;
+  if (!c->use_side || !gates_now(c)) return;
+  c->sq_wait = ++c->sig_seq;
+  c->pending_sig = c->sq_wait;
+}
+// the kernel about to be enqueued on the caller's stream publishes the pending progress value
+void take_sig(eae_ctx* c, ConvArgs& a) {
+  if (!c->pending_sig) return;
+  a.sig = c->sigwords; a.sig_val = c->pending_sig;
+  c->pending_sig = 0;
+}
+int sq_commit(eae_ctx* c, hipStream_t st) {
+  c->sq_forked = false;
+  if (c->sq_items.empty()) return 0;
+  int rc = 0;
+  if (!c->use_side) {
+    for (auto& it : c->sq_items) if (!rc) rc = it.fn(st, c->wscratch);
+    c->sq_items.clear();
+    return rc;
+  }
+  const int ns = 1 + c->nx;
+  // members -> streams
+  std::vector<int> where(c->sq_items.size());
+  unsigned used = 0;
+  for (size_t i = 0; i < c->sq_items.size(); ++i) {
+    where[i] = c->sq_items[i].pin >= 0 ? c->sq_items[i].pin : (c->side_rr++ % ns);
+    used |= 1u << where[i];
+  }
+  if (gates_now(c)) {
+    if (!c->sq_wait) { c->sq_wait = ++c->sig_seq; c->pending_sig = c->sq_wait; }      // commit without a fork: order after `st` as it stands
+    if (c->pending_sig) {                      // no kernel of the caller's stream carried the value: publish it with a kernel of its own
+      RC(eae_launch_signal(st, c->sigwords, c->pending_sig));
+      c->pending_sig = 0;
+    }
+    GateArgs g = GateArgs();
+    g.word[0] = c->sigwords; g.want[0] = c->sq_wait; g.n = 1; g.timeout = c->sigwords + 8;
+    for (int k = 0; k < ns; ++k) if (used & (1u << k)) RC(eae_launch_gate(side_stream(c, k), g));
+  } else {
+    hipEvent_t ev = c->ev_fork[c->ev_i];
+    c->ev_i = (c->ev_i + 1) % eae_ctx::NEV;
+    EAE_HIP(hipEventRecord(ev, st));
+    for (int k = 0; k < ns; ++k) if (used & (1u << k)) EAE_HIP(hipStreamWaitEvent(side_stream(c, k), ev, 0));
+  }
+  c->sq_wait = 0;
+  c->side_used |= used;
+  for (size_t i = 0; i < c->sq_items.size(); ++i)
+    if (!rc) rc = c->sq_items[i].fn(side_stream(c, where[i]), where[i] == 0 ? c->wscratch : c->wscratchx[where[i] - 1]);
+  c->sq_items.clear();
+  return rc;
 }
 // everything enqueued so far on the extra side streams completes before later work on the first one (the DP path hands
 // `side` to the all-reduce)
@@ -442,15 +522,32 @@ int fold_side2(eae_ctx* c) {
   }
   return 0;
 }
-// join: work enqueued on `st` from now on starts after everything enqueued so far on the side streams
+// join: work enqueued on `st` from now on starts after everything enqueued so far on the side streams.  With gates: every side
+// stream that received work publishes a done-counter with a one-thread kernel, ONE gate on `st` waits for all of them.
 int join_side(eae_ctx* c, hipStream_t st) {
   if (!c->use_side) return 0;
+  RC(sq_commit(c, st));
+  const int ns = 1 + c->nx;
+  if (gates_now(c)) {
+    GateArgs g = GateArgs();
+    g.timeout = c->sigwords + 8;
+    for (int k = 0; k < ns; ++k) {
+      if (!(c->side_used & (1u << k))) continue;
+      c->side_done_seq[k] += 1;
+      RC(eae_launch_signal(side_stream(c, k), c->sigwords + 1 + k, c->side_done_seq[k]));
+      g.word[g.n] = c->sigwords + 1 + k; g.want[g.n] = c->side_done_seq[k]; g.n++;
+    }
+    if (g.n) RC(eae_launch_gate(st, g));
+    c->side_used = 0;
+    return 0;
+  }
   EAE_HIP(hipEventRecord(c->ev_join, c->side));
   EAE_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
   for (int i = 0; i < c->nx; ++i) {
     EAE_HIP(hipEventRecord(c->ev_joinx[i], c->sidex[i]));
     EAE_HIP(hipStreamWaitEvent(st, c->ev_joinx[i], 0));
   }
+  c->side_used = 0;
   return 0;
 }
 
@@ -580,7 +677,9 @@ int run_decoder(eae_ctx* c, hipStream_t st, const float* z, int B, bool train, c
     f.M = B; f.N = (int)c->K; f.K = c->L; f.klen = c->L;
     f.c = ConvArgs();
     f.c.out = c->d0; f.c.bias = (const float*)(c->pack + c->pk_bd);
+    take_sig(c, f.c);
     RC(eae_launch_fc_nt(st, f, SRC_F32, FCE_BIAS_BF16, 1));
+    RC(sq_commit(c, st));          // the classification head (queued by forward_impl) starts beside the decoder
   }
   const int cin[3] = {256, 128, 64};
   for (int i = 0; i < 3; ++i) {
@@ -649,10 +748,14 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
   // (ev_head) right before dz_cls is added to dz.  (head_kernel is built without packed-FP32 instructions, see EAE_NO_PK.)
   if (head) {
     if (want_grad && c->head_side && c->use_side) {
-      hipStream_t hs;
-      RC(fork_side(c, st, &hs));
-      RC(run_head(c, hs, B, io->labels, io->logits, want_grad, nullptr));
-      EAE_HIP(hipEventRecord(c->ev_head, hs));
+      const long long* labels = io->labels;
+      float* logits = io->logits;
+      sq_push(c, [=](hipStream_t hs, float*) {
+        RC(run_head(c, hs, B, labels, logits, true, nullptr));
+        EAE_HIP(hipEventRecord(c->ev_head, hs));
+        return 0;
+      }, 0);
+      sq_fork(c);                  // released by the decoder's first kernel (run_decoder commits behind it)
       c->head_pending = true;
     } else {
       RC(run_head(c, st, B, io->labels, io->logits, want_grad, nullptr));
@@ -664,49 +767,21 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
     const int n_ce = (head && io->labels) ? eae_head_blocks(B) : 0;
     // in a gradient step nothing on the main stream reads what this kernel writes (deconv4 bias gradient, loss scalars):
     // it goes to the side stream, which backward_impl joins before the optimizer
-    hipStream_t ls = st;
-    if (want_grad) { RC(fork_side(c, st, &ls)); c->side_forked = c->use_side; }
-    RC(eae_launch_loss_finalize(ls, c->msepart, eae_edge_tiles(B, c->H, c->W), c->cepart, n_ce, io->alpha, numel, B,
-                                want_grad ? c->G + c->poff[33] : nullptr, io->loss_accum, io->loss_last));
+    if (want_grad && c->use_side) {
+      const float alpha = io->alpha;
+      float *accum = io->loss_accum, *last = io->loss_last;
+      const int ntile = eae_edge_tiles(B, c->H, c->W);
+      sq_push(c, [=](hipStream_t ls, float*) {
+        return eae_launch_loss_finalize(ls, c->msepart, ntile, c->cepart, n_ce, alpha, numel, B, c->G + c->poff[33], accum, last);
+      }, 0);
+      sq_fork(c);                  // released by the first kernel of the backward-data chain (backward_impl commits behind it)
+    } else {
+      RC(eae_launch_loss_finalize(st, c->msepart, eae_edge_tiles(B, c->H, c->W), c->cepart, n_ce, io->alpha, numel, B,
+                                  want_grad ? c->G + c->poff[33] : nullptr, io->loss_accum, io->loss_last));
+    }
   }
   return 0;
 }
-
-// Side work (weight gradients, their slice reductions, the head-gradient reduction) only feeds the optimizer, so it runs on the
-// engine's side streams beside the backward-data chain.  Every hand-over costs the chain one event record on the caller's
-// stream (~5 us of bubble each, tools/timeline.py), so the launches are QUEUED and handed over in groups: one record per group,
-// waited on by every side stream that receives a member.  Members go round-robin over the side streams (each stream has its own
-// split-K scratch: a weight gradient and its slice reduction stay on one stream).
-struct SideQueue {
-  eae_ctx* c;
-  hipStream_t main;
-  std::vector<std::function<int(hipStream_t, float*)>> items;
-  void push(std::function<int(hipStream_t, float*)> f) { items.push_back(std::move(f)); }
-  int flush() {
-    if (items.empty()) return 0;
-    int rc = 0;
-    if (!c->use_side) {
-      for (auto& f : items) if (!rc) rc = f(main, c->wscratch);
-      items.clear();
-      return rc;
-    }
-    const int ns = 1 + c->nx;
-    hipEvent_t ev = c->ev_fork[c->ev_i];
-    c->ev_i = (c->ev_i + 1) % eae_ctx::NEV;
-    EAE_HIP(hipEventRecord(ev, main));
-    const int used = (int)items.size() < ns ? (int)items.size() : ns;
-    for (int k = 0; k < used; ++k) {
-      const int sidx = (c->side_rr + k) % ns;
-      EAE_HIP(hipStreamWaitEvent(sidx == 0 ? c->side : c->sidex[sidx - 1], ev, 0));
-    }
-    for (auto& f : items) {
-      const int sidx = c->side_rr++ % ns;
-      if (!rc) rc = f(sidx == 0 ? c->side : c->sidex[sidx - 1], sidx == 0 ? c->wscratch : c->wscratchx[sidx - 1]);
-    }
-    items.clear();
-    return rc;
-  }
-};
 
 // part 0 = everything, 1 = classifier + decoder + dec.fc (gradient tensors 18..37), 2 = enc.fc + encoder (tensors 0..17)
 int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float* dz_ext = nullptr, int part = 0) {
@@ -717,38 +792,44 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
   // 12-wave weight-gradient kernels running back to back on the side streams take away from the backward-data chain.
   static const bool fork_every = getenv("EAE_FORK_GROUPS") == nullptr;
   const bool dp = part != 0 || c->dp_stream[0] != nullptr || c->dp_stream[1] != nullptr;
-  SideQueue sq{c, st, {}};
-  auto maybe_flush = [&]() -> int { return fork_every ? sq.flush() : 0; };
-  c->side_rr = 0;
+  // fork() = "this group may start now" when every weight gradient is handed over by itself
+  auto fork_if_every = [&]() { if (fork_every) sq_fork(c); };
   if (part != 2) {
-    // ---- first group: forward_impl forked `side` at this very position of the main stream for the loss finalize
-    hipStream_t ss;
-    if (c->side_forked) ss = c->side;
-    else RC(fork_side(c, st, &ss));
-    c->side_forked = false;
-    c->side_rr = 1;                // the first queued group starts the round-robin at side stream #1
-    // classifier weight gradients (partials written by the head kernel)
+    // ---- first group (side stream 0, behind the loss bookkeeping forward_impl queued): classifier weight gradients from the
+    //      head kernel's partials, deconv4's weight gradient.  Released by the first kernel of the backward-data chain.
+    c->side_rr = 1;                // the round robin of the later groups starts at side stream #1
     if (head) {
-      const int nb = eae_head_blocks(B);
-      hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(c->head_stride / 4)), dim3(256), 0, ss, c->headpart, nb,
-                         (long)(c->head_stride / 4), c->G + c->poff[34], 1.0f);
-      EAE_LAUNCH_CHECK();
+      sq_push(c, [=](hipStream_t ss, float*) {
+        const int nb = eae_head_blocks(B);
+        hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(c->head_stride / 4)), dim3(256), 0, ss, c->headpart, nb,
+                           (long)(c->head_stride / 4), c->G + c->poff[34], 1.0f);
+        EAE_LAUNCH_CHECK();
+        return 0;
+      }, 0);
     } else {
-      EAE_HIP(hipMemsetAsync(c->G + c->poff[34], 0, (size_t)(c->poff[38] - c->poff[34]) * 4, ss));
+      sq_push(c, [=](hipStream_t ss, float*) {
+        EAE_HIP(hipMemsetAsync(c->G + c->poff[34], 0, (size_t)(c->poff[38] - c->poff[34]) * 4, ss));
+        return 0;
+      }, 0);
     }
-    // ---- deconv4: weight gradient, then backward-data into u[2]'s BN+ReLU
-    RC(eae_launch_edge_wgrad(ss, SRC3_NHWC4_BF16, c->g4, B, H, W, src_bnrelu(c->u[2], c->coef_f[6]), SRC_BNRELU, c->wscratch,
-                             c->wscratch_floats, c->G + c->poff[32]));
+    sq_push(c, [=](hipStream_t ss, float* scr) {
+      return eae_launch_edge_wgrad(ss, SRC3_NHWC4_BF16, c->g4, B, H, W, src_bnrelu(c->u[2], c->coef_f[6]), SRC_BNRELU, scr,
+                                   c->wscratch_floats, c->G + c->poff[32]);
+    }, 0);
+    sq_fork(c);
+    // ---- deconv4: backward-data into u[2]'s BN+ReLU
     {
       EdgeArgs a;
       a.src3 = c->g4; a.B = B; a.H = H; a.W = W;
       a.c = ConvArgs();
       a.c.wpack = (const bf16_t*)(c->pack + c->pk_d4k); a.c.out = c->gu[2]; a.c.stat_part = c->stat;
       a.c.yprev = c->u[2]; a.c.prev_coef = c->coef_f[6]; a.c.B = B;
+      take_sig(c, a.c);
       {
         ProfBracket pb(c, EAE_PROF_DECONV4_BWD, st);
         RC(eae_launch_edge_conv(st, SRC3_NHWC4_BF16, EPI_MASK, a));
       }
+      RC(sq_commit(c, st));
       RC(bn_bwd_fin(c, st, 6, eae_edge_tiles(B, H, W), (long long)B * (H / 2) * (W / 2)));
     }
     // ---- deconv3, deconv2, deconv1 (i = 2, 1, 0): weight gradients queued, handed over together before the last dgrad
@@ -756,7 +837,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     for (int i = 2; i >= 0; --i) {
       const int cs = dcin[i], cb = dcin[i] / 2;         // deconv weight [cs][cb][3][3]
       const int Hs = H >> (4 - i), Ws = W >> (4 - i);   // input (small) map of the deconv
-      sq.push([=](hipStream_t s2, float* scr) {          // needs coef_b[4+i] (BN-backward finalize of this layer's output)
+      sq_push(c, [=](hipStream_t s2, float* scr) {       // needs coef_b[4+i] (BN-backward finalize of this layer's output)
         WgradArgs w = WgradArgs();
         w.small = (i == 0) ? src_raw(c->d0) : src_bnrelu(c->u[i - 1], c->coef_f[3 + i]);
         w.big = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
@@ -764,41 +845,47 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
         return eae_launch_wgrad_s2(s2, w, cs, cb, i == 0 ? SRC_RAW : SRC_BNRELU, SRC_BNBWD, scr, c->wscratch_floats, c->G + c->poff[20 + 4 * i],
                                    prof_hook_for(c, i == 2 ? EAE_PROF_DECONV3_WGRAD : -1));
       });
-      if (i == 0) RC(sq.flush()); else RC(maybe_flush());
+      if (i == 0) sq_fork(c); else fork_if_every();
       ConvArgs a = ConvArgs();
       a.src = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
       a.wpack = (const bf16_t*)(c->pack + c->pk_p1[3 + i]);
       a.B = B; a.Hin = Hs * 2; a.Win = Ws * 2;
+      take_sig(c, a);
       if (i > 0) {
         a.out = c->gu[i - 1]; a.stat_part = c->stat; a.yprev = c->u[i - 1]; a.prev_coef = c->coef_f[3 + i];
         {
           ProfBracket pb(c, i == 2 ? EAE_PROF_DECONV3_BWD : -1, st);
           RC(eae_launch_conv_s2(a, cb, cs, SRC_BNBWD, EPI_MASK, st));
         }
+        if (c->sq_forked) RC(sq_commit(c, st));
         RC(bn_bwd_fin(c, st, 3 + i, eae_conv_s2_ntiles(0, B, a.Hin, a.Win), (long long)B * Hs * Ws));
       } else {
         a.out = c->gd0;
         RC(eae_launch_conv_s2(a, cb, cs, SRC_BNBWD, EPI_PLAIN, st));
+        if (c->sq_forked) RC(sq_commit(c, st));
       }
     }
     // ---- dec.fc: weight/bias gradient (queued: needs gd0) and dz
-    sq.push([=](hipStream_t s2, float*) {
+    sq_push(c, [=](hipStream_t s2, float*) {
       FcTnArgs t = FcTnArgs();
       t.p = src_raw(c->gd0); t.q = src_f32(c->z); t.Bt = B; t.I = (int)c->K; t.J = c->L;
       t.out = c->G + c->poff[18]; t.colsum = c->G + c->poff[19]; t.out_mode = 0; t.Pn = (int)c->Pn;
       return eae_launch_fc_tn(s2, t, SRC_RAW, SRC_F32);
     });
-    RC(maybe_flush());
+    fork_if_every();
     {
       FcNtArgs f = FcNtArgs();
       f.a = src_raw(c->gd0); f.w = (const bf16_t*)(c->pack + c->pk_wd2);
       f.M = B; f.N = c->L; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
+      f.c = ConvArgs();
+      take_sig(c, f.c);
       const int ksplit = (int)(c->K / 128);
       RC(eae_launch_fc_nt(st, f, SRC_RAW, FCE_PARTIAL, ksplit));
+      if (c->sq_forked) RC(sq_commit(c, st));
       if (c->head_pending) { EAE_HIP(hipStreamWaitEvent(st, c->ev_head, 0)); c->head_pending = false; }
       RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, nullptr, head ? c->dzc : nullptr, dz_ext, c->dz));
     }
-    if (dp) RC(sq.flush());        // the hand-off below covers gradient tensors 18..37 only
+    if (dp) RC(sq_commit(c, st));  // the hand-off below covers gradient tensors 18..37 only (ordered after `st` as it stands)
   }   // part != 2
   if (part == 1) return fold_side2(c);     // the caller may now all-reduce gradient tensors 18..37 behind the side stream
   if (part == 0 && c->dp_stream[0]) {      // same hand-off without splitting the call: see eae_dp_stream()
@@ -807,20 +894,22 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     EAE_HIP(hipStreamWaitEvent(c->dp_stream[0], c->ev_part[0], 0));
   }
   // ---- enc.fc: weight/bias gradient (queued with the dec.fc one: needs dz) and backward-data into y[3]'s BN+ReLU
-  sq.push([=](hipStream_t s2, float*) {
+  sq_push(c, [=](hipStream_t s2, float*) {
     FcTnArgs t = FcTnArgs();
     t.p = src_f32(c->dz); t.q = src_bnrelu(c->y[3], c->coef_f[3]); t.Bt = B; t.I = c->L; t.J = (int)c->K;
     t.out = c->G + c->poff[16]; t.colsum = c->G + c->poff[17]; t.out_mode = 1; t.Pn = (int)c->Pn;
     return eae_launch_fc_tn(s2, t, SRC_F32, SRC_BNRELU);
   });
-  RC(sq.flush());
+  sq_fork(c);
   {
     FcNtArgs f = FcNtArgs();
     f.a = src_f32(c->dz); f.w = (const bf16_t*)(c->pack + c->pk_we2);
     f.M = B; f.N = (int)c->K; f.K = c->L; f.klen = c->L;
     f.c = ConvArgs();
     f.c.out = c->gy[3]; f.c.stat_part = c->stat; f.c.yprev = c->y[3]; f.c.prev_coef = c->coef_f[3];
+    take_sig(c, f.c);
     RC(eae_launch_fc_nt(st, f, SRC_F32, FCE_MASK, 1));
+    RC(sq_commit(c, st));
     RC(bn_bwd_fin(c, st, 3, ((B + 127) / 128) * (int)c->Pn, (long long)B * c->Pn));
   }
   // ---- conv4, conv3, conv2 (i = 3, 2, 1): weight gradient (queued; conv4 + conv3 go together, conv2 before the last dgrad so
@@ -828,7 +917,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
   for (int i = 3; i >= 1; --i) {
     const int cs = ENC_C[i + 1], cb = ENC_C[i];       // conv weight [cs][cb][3][3]
     const int Hs = H >> (i + 1), Ws = W >> (i + 1);   // output (small) map of the conv
-    sq.push([=](hipStream_t s2, float* scr) {            // needs coef_b[i]
+    sq_push(c, [=](hipStream_t s2, float* scr) {         // needs coef_b[i]
       WgradArgs w = WgradArgs();
       w.small = src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
       w.big = src_bnrelu(c->y[i - 1], c->coef_f[i - 1]);
@@ -836,16 +925,18 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
       return eae_launch_wgrad_s2(s2, w, cs, cb, SRC_BNBWD, SRC_BNRELU, scr, c->wscratch_floats, c->G + c->poff[4 * i],
                                  prof_hook_for(c, i == 1 ? EAE_PROF_CONV2_WGRAD : -1));
     });
-    if (i != 3) RC(sq.flush()); else RC(maybe_flush());
+    if (i != 3) sq_fork(c); else fork_if_every();
     ConvArgs a = ConvArgs();
     a.src = src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
     a.wpack = (const bf16_t*)(c->pack + c->pk_p2[i - 1]);
     a.out = c->gy[i - 1]; a.stat_part = c->stat; a.yprev = c->y[i - 1]; a.prev_coef = c->coef_f[i - 1];
     a.B = B; a.Hin = Hs; a.Win = Ws;
+    take_sig(c, a);
     {
       ProfBracket pb(c, i == 1 ? EAE_PROF_CONV2_BWD : -1, st);
       RC(eae_launch_deconv_s2(a, cs, cb, SRC_BNBWD, EPI_MASK, st));
     }
+    if (c->sq_forked) RC(sq_commit(c, st));
     RC(bn_bwd_fin(c, st, i - 1, eae_conv_s2_ntiles(1, B, Hs, Ws, cs), (long long)B * (Hs * 2) * (Ws * 2)));
     if (i == 2 && part == 0 && c->dp_stream[1]) {     // enc.fc, conv4 and conv3 weight gradients have been enqueued
       RC(fold_side2(c));

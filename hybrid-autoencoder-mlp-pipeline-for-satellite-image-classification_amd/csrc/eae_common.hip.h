@@ -233,4 +233,10 @@ __device__ __forceinline__ void bn_fold_fwd(const BnFold& f, float* table, long 
   bn_fold_fwd_finish<C>(f, r, table, red, writer);
 }
 
+// first thread of the grid publishes the stream's progress value (relaxed agent-scope store: bypasses the non-coherent caches)
+__device__ __forceinline__ void eae_signal(unsigned* sig, unsigned val) {
+  if (sig != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+    __hip_atomic_store(sig, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #define EAE_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return eae_set_error(-3, hipGetErrorString(e__)); } while (0)

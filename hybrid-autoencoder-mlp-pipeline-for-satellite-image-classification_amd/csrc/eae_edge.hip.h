@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void edge_conv_kernel(EdgeArgs a) {
   const int tyb = t % tiles_y; t /= tiles_y;
   const int n = t;
   const int kgl = lane >> 4;
+  eae_signal(a.c.sig, a.c.sig_val);
   // weight fragments first (independent of the patch): A[channel][k], 2 m-tiles x 2 k-steps
   bf16x8 wf[2][2];
 #pragma unroll

@@ -49,6 +49,7 @@ __device__ __forceinline__ uint4 fc_load_a(const SrcDesc& s, size_t off, bool va
 // tile 128 (M) x 64 (N); 4 waves 2x2 (each 64 x 32); K chunks of 64
 template <int AMODE, int EPI>
 __global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs a) {
+  eae_signal(a.c.sig, a.c.sig_val);
   __shared__ __attribute__((aligned(16))) bf16_t al[128 * FC_LS];      // A chunk; later the output tile [128][72]
   __shared__ __attribute__((aligned(16))) bf16_t wl[64 * FC_LS];
   __shared__ __attribute__((aligned(16))) float red[2 * 32 * 64];

@@ -32,6 +32,11 @@ struct ConvArgs {
   const bf16_t* yprev;     // EPI_MASK: raw pre-BN tensor at the output positions
   const float* prev_coef;  // EPI_MASK: [4][COUT] s,t,mean,invstd of that BN
   int B, Hin, Win;         // input spatial size (conv: out = Hin/2; deconv: out = 2*Hin)
+  // Progress word of the caller's stream: the first thread of the grid stores `sig_val` there when the kernel STARTS (i.e. after
+  // everything enqueued before it on its stream has completed).  Gate kernels on the engine's side streams poll that word, so a
+  // hand-over to a side stream needs no event record on the dependency chain (each one cost it ~5 us of bubble).
+  unsigned* sig;
+  unsigned sig_val;
   BnAcc bacc;              // statistics go to fixed-point accumulators instead of stat_part (finalize folded into the consumer)
   BnFold fold;             // SRC_BNRELU: build the source layer's coefficient table from its accumulators
 #ifdef EAE_STAMPS
@@ -236,6 +241,7 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
   const int n0 = nblk * BN;
   const int iy0 = (KIND == KIND_CONV) ? 2 * tyb * TH - 1 : tyb * TH, ix0 = (KIND == KIND_CONV) ? 2 * txb * TW - 1 : txb * TW;
 
+  eae_signal(a.sig, a.sig_val);
   EAE_STAMP(0);
   EAE_STAMP_WG(0);
   f32x4 acc[NPH][MT];

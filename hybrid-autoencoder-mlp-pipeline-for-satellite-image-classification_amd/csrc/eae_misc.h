@@ -22,6 +22,9 @@ int eae_launch_bn_bwd_finalize(hipStream_t st, const float* part, int ntiles, in
 int eae_launch_bn_bwd_reduce(hipStream_t st, const float* part, int ntiles, int C, double* sums, float* dgamma, float* dbeta);
 int eae_launch_bn_bwd_coef(hipStream_t st, const double* sums, int C, long long count, const float* gamma, const float* coef_fwd,
                            float* coef_bwd);
+struct GateArgs { unsigned* word[4]; unsigned want[4]; int n; unsigned* timeout; };
+int eae_launch_gate(hipStream_t st, const GateArgs& g);
+int eae_launch_signal(hipStream_t st, unsigned* word, unsigned val);
 int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base);
 int eae_launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
                     double eps, double wd, long long step);

@@ -160,6 +160,38 @@ int eae_launch_bn_bwd_finalize(hipStream_t st, const float* part, int ntiles, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Device-side stream dependencies.  gate_kernel: one lane polls up to 4 progress words (relaxed agent-scope loads, s_sleep
+// between polls) until each has reached its value; the kernels behind it on the same stream then see everything the signalling
+// stream had completed when it published the value (kernel-boundary acquire).  Values only grow (wrap-safe signed compare).
+// The spin is bounded: after ~2 s the gate gives up and records the value it was waiting for in `timeout` (the step's
+// results are then wrong; eae_gate_timeouts() reports it).  signal_kernel publishes a value from a stream that has no
+// other kernel to carry it.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ EAE_NO_PK __launch_bounds__(64) void gate_kernel(GateArgs g) {
+  if (threadIdx.x != 0) return;
+  for (int k = 0; k < g.n; ++k) {
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(g.word[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.want[k]) < 0) {
+      __builtin_amdgcn_s_sleep(16);
+      if (++spins > (1u << 22)) { atomicExch(g.timeout, g.want[k] ? g.want[k] : 1u); return; }
+    }
+  }
+}
+__global__ EAE_NO_PK void signal_kernel(unsigned* word, unsigned val) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+int eae_launch_gate(hipStream_t st, const GateArgs& g) {
+  hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, st, g);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+int eae_launch_signal(hipStream_t st, unsigned* word, unsigned val) {
+  hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, st, word, val);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Weight packing: one launch converts every fp32 master weight into the bf16 layouts the kernels read.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pack_fetch(const PackDesc& d, const float* __restrict__ src, long i) {

@@ -160,6 +160,11 @@ class AEEngine:
     def params_changed(self):
         check(self.lib.eae_params_changed(self.ctx))
 
+    def gate_timeouts(self):
+        """0, or the progress value a side-stream gate gave up waiting for (diagnostic; synchronises the device)."""
+        with torch.cuda.device(self.device):
+            return int(self.lib.eae_gate_timeouts(self.ctx))
+
     def generation(self):
         """Id of the most recent forward (eae_ae_backward only differentiates the resident one)."""
         return int(self.lib.eae_forward_generation(self.ctx))

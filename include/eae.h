@@ -55,6 +55,10 @@ int eae_destroy(eae_ctx* ctx);
  * bn_nbt: int64[7] num_batches_tracked. */
 int eae_bind(eae_ctx* ctx, float* params, float* grads, float* adam_m, float* adam_v, float* bn_running,
              long long* bn_nbt);
+/* The engine orders its side streams behind the caller's stream with one-wave GATE kernels that poll a device progress word
+ * (no event record on the caller's stream; EAE_FORK_EVENTS=1 restores events).  Their spin is bounded (~2 s): this diagnostic
+ * synchronises the device and returns 0, or the value a gate gave up waiting for (the gradients of that step are wrong). */
+long long eae_gate_timeouts(eae_ctx* ctx);
 /* The host changed parameter values (load_state_dict, optimizer outside the engine): repack before next use. */
 int eae_params_changed(eae_ctx* ctx);
 int eae_set_adam_step(eae_ctx* ctx, long long step);

@@ -319,6 +319,7 @@ def test_determinism():
         for s in range(2):
             eng.train_step(_cuda(x), _cuda(y), 35.0, 5e-3)
         torch.cuda.synchronize()
+        assert eng.gate_timeouts() == 0
         outs.append(eng.params.cpu().numpy().copy())
     assert np.array_equal(outs[0], outs[1])
 
