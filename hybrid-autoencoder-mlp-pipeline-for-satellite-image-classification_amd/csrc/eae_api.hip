@@ -211,8 +211,8 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   size_t o_acc[7], acc_total = 0;
   {
     const int Bi = (int)Bm;
-    const int nt[7] = {eae_edge_tiles(Bi, c->H, c->W), eae_conv_s2_ntiles(0, Bi, c->H / 2, c->W / 2), eae_conv_s2_ntiles(0, Bi, c->H / 4, c->W / 4),
-                       eae_conv_s2_ntiles(0, Bi, c->H / 8, c->W / 8), eae_conv_s2_ntiles(1, Bi, c->H / 16, c->W / 16),
+    const int nt[7] = {eae_edge_tiles(Bi, c->H, c->W), eae_conv_s2_ntiles(0, Bi, c->H / 2, c->W / 2), eae_conv_s2_ntiles(0, Bi, c->H / 4, c->W / 4, 64),
+                       eae_conv_s2_ntiles(0, Bi, c->H / 8, c->W / 8, 128), eae_conv_s2_ntiles(1, Bi, c->H / 16, c->W / 16),
                        eae_conv_s2_ntiles(1, Bi, c->H / 8, c->W / 8), eae_conv_s2_ntiles(1, Bi, c->H / 4, c->W / 4, 64)};
     for (int l = 0; l < 7; ++l) {
       int cp = 8;
@@ -651,7 +651,7 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
       RC(eae_launch_conv_s2(a, ENC_C[i], ENC_C[i + 1], SRC_BNRELU, EPI_FWD, st));
     }
     RC(sync_fwd(c, st, i, train));
-    RC(bn_fwd_finalize(c, st, i, eae_conv_s2_ntiles(0, B, a.Hin, a.Win), (long long)B * (a.Hin / 2) * (a.Win / 2), train));
+    RC(bn_fwd_finalize(c, st, i, eae_conv_s2_ntiles(0, B, a.Hin, a.Win, ENC_C[i]), (long long)B * (a.Hin / 2) * (a.Win / 2), train));
   }
   FcNtArgs f = FcNtArgs();
   f.a = src_bnrelu(c->y[3], c->coef_f[3]);
@@ -858,7 +858,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
           RC(eae_launch_conv_s2(a, cb, cs, SRC_BNBWD, EPI_MASK, st));
         }
         if (c->sq_forked) RC(sq_commit(c, st));
-        RC(bn_bwd_fin(c, st, 3 + i, eae_conv_s2_ntiles(0, B, a.Hin, a.Win), (long long)B * Hs * Ws));
+        RC(bn_bwd_fin(c, st, 3 + i, eae_conv_s2_ntiles(0, B, a.Hin, a.Win, cb), (long long)B * Hs * Ws));
       } else {
         a.out = c->gd0;
         RC(eae_launch_conv_s2(a, cb, cs, SRC_BNBWD, EPI_PLAIN, st));

@@ -21,11 +21,19 @@ int launch(const ConvArgs& a, hipStream_t st) {   // NOLINT
   return 0;
 }
 
+// EAE_IG_SMALL (bit mask, experiments): 1 = 64-position tiles for the conv kind on 8x8 / 4x4 output maps (twice the workgroups),
+// 2 = 32-channel blocks for the transposed kind on 8x8 / 4x4 input maps (twice the workgroups)
+static int ig_small() { static const int v = getenv("EAE_IG_SMALL") ? atoi(getenv("EAE_IG_SMALL")) : 0; return v; }
+
 // geometry by the size of the position grid (conv: output map; deconv: input map)
 template <int CIN, int COUT, int BN, int SRC, int EPI>
 int conv_geo(const ConvArgs& a, hipStream_t st) {
   const int Hp = a.Hin / 2, Wp = a.Win / 2;
   if (Wp % 16 == 0 && Hp % 8 == 0) return launch<KIND_CONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st);
+  if constexpr (CIN >= 64) {
+    if (Wp == 8 && Hp == 8 && (ig_small() & 1)) return launch<KIND_CONV, CIN, COUT, BN, 8, 8, 1, SRC, EPI>(a, st);
+    if (Wp == 4 && Hp == 4 && (ig_small() & 1)) return launch<KIND_CONV, CIN, COUT, BN, 4, 4, 4, SRC, EPI>(a, st);
+  }
   if (Wp == 8 && Hp == 8) return launch<KIND_CONV, CIN, COUT, BN, 8, 8, 2, SRC, EPI>(a, st);
   if (Wp == 4 && Hp == 4) return launch<KIND_CONV, CIN, COUT, BN, 4, 4, 8, SRC, EPI>(a, st);
   return eae_set_error(-2, "conv_s2: unsupported spatial size (output must be 4x4, 8x8 or a multiple of 8x16)");
@@ -74,6 +82,12 @@ int eae_launch_conv_s2(const ConvArgs& a, int cin, int cout, int src, int epi, h
 int eae_launch_deconv_s2(const ConvArgs& a, int cin, int cout, int src, int epi, hipStream_t st) {
   if (a.B <= 0) return eae_set_error(-2, "deconv_s2: bad shape");
 #define CASE(CI, CO, BN_, S, E) if (cin == CI && cout == CO && src == S && epi == E) return deconv_geo<CI, CO, BN_, S, E>(a, st)
+  if ((ig_small() & 2) && a.Win <= 8) {
+    CASE(256, 128, 32, SRC_RAW, EPI_FWD);
+    CASE(128, 64, 32, SRC_BNRELU, EPI_FWD);
+    CASE(256, 128, 32, SRC_BNBWD, EPI_MASK);
+    CASE(128, 64, 32, SRC_BNBWD, EPI_MASK);
+  }
   CASE(256, 128, 64, SRC_RAW, EPI_FWD);
   CASE(128, 64, 64, SRC_BNRELU, EPI_FWD);
   CASE(64, 32, 32, SRC_BNRELU, EPI_FWD);
@@ -91,6 +105,10 @@ int eae_conv_s2_ntiles(int kind, int B, int Hin, int Win, int cin) {
   if (kind == 0) {
     int Hp = Hin / 2, Wp = Win / 2;
     if (Wp % 16 == 0 && Hp % 8 == 0) return B * (Hp / 8) * (Wp / 16);
+    if (cin >= 64 && (ig_small() & 1)) {
+      if (Wp == 8 && Hp == 8) return B;
+      if (Wp == 4 && Hp == 4) return (B + 3) / 4;
+    }
     if (Wp == 8 && Hp == 8) return (B + 1) / 2;
     if (Wp == 4 && Hp == 4) return (B + 7) / 8;
     return -1;
