@@ -180,11 +180,12 @@ __device__ __forceinline__ void bn_acc_add(const BnAcc& b, int C, int tile_id, i
 // flight.  copies <= 4 * (256 / C)  (at most 4 accumulator sets per thread).
 constexpr int BN_FOLD_K = 4;
 struct BnFoldRegs { long long v[2][BN_FOLD_K]; };
+// `tid` = index of the calling thread among the 256 threads that build the table (default: the whole 256-thread workgroup)
 template <int C>
-__device__ __forceinline__ void bn_fold_load(const BnFold& f, BnFoldRegs& r) {
+__device__ __forceinline__ void bn_fold_load(const BnFold& f, BnFoldRegs& r, int tid = threadIdx.x) {
   static_assert(C <= 256 && 256 % C == 0, "channel count");
   constexpr int G = 256 / C;
-  const int tid = threadIdx.x, ch = tid % C, grp = tid / C;
+  const int ch = tid % C, grp = tid / C;
 #pragma unroll
   for (int j = 0; j < BN_FOLD_K; ++j) {
     const int k = grp + j * G;
@@ -194,10 +195,12 @@ __device__ __forceinline__ void bn_fold_load(const BnFold& f, BnFoldRegs& r) {
   }
 }
 // All 256 threads of the workgroup.  table = LDS float [4][C]; red = LDS long long [2][256] (may alias any idle buffer).
+// (contains two workgroup barriers: every wave of the workgroup has to pass them, table builders or not)
 template <int C>
-__device__ __forceinline__ void bn_fold_fwd_finish(const BnFold& f, const BnFoldRegs& r, float* table, long long* red, bool writer) {
+__device__ __forceinline__ void bn_fold_fwd_finish(const BnFold& f, const BnFoldRegs& r, float* table, long long* red, bool writer,
+                                                   int tid = threadIdx.x) {
   constexpr int G = 256 / C;
-  const int tid = threadIdx.x, ch = tid % C, grp = tid / C;
+  const int ch = tid % C, grp = tid / C;
   long long s1 = 0, s2 = 0;
 #pragma unroll
   for (int j = 0; j < BN_FOLD_K; ++j) { s1 += r.v[0][j]; s2 += r.v[1][j]; }

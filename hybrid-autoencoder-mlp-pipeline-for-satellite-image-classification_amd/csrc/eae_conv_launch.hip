@@ -1,6 +1,7 @@
 // Host-side dispatch of the unified stride-2 conv / transposed-conv implicit-GEMM kernel (eae_igemm.hip.h).
 #include "eae_internal.h"
 #include "eae_igemm.hip.h"
+#include "eae_igemm2.hip.h"
 #include <cstdlib>
 
 namespace {
@@ -21,6 +22,34 @@ int launch(const ConvArgs& a, hipStream_t st) {   // NOLINT
   return 0;
 }
 
+// Wave-specialised kernel (eae_igemm2.hip.h) for the multi-chunk layers on the small maps.  Inside the training step (rocprofv3,
+// B=512, us, igemm2 vs one-role kernel): conv 128->256 forward 16.7 vs 18.3 and deconv 256->128 forward 16.5 vs 18.2 win; conv
+// 64->128 forward 18.5 vs 16.8, deconv 128->64 forward 22.6 vs 19.6, and every backward-data use (31.3 vs 26.2, 48.8 vs 33.6: a
+// 512-thread workgroup owns the whole CU and collides with the weight-gradient kernels beside it) lose.  So: EAE_IGEMM2 unset / 1 =
+// the two winning forward layers only, 2 = every layer it is instantiated for, 0 = one-role kernel everywhere.
+static int igemm2_mode() { static const int v = getenv("EAE_IGEMM2") ? atoi(getenv("EAE_IGEMM2")) : 1; return v; }
+template <int KIND, int CIN, int EPI>
+static bool igemm2_on() {
+  constexpr bool wins = (EPI == EPI_FWD) && ((KIND == KIND_CONV && CIN == 128) || (KIND == KIND_DECONV && CIN == 256));
+  return igemm2_mode() >= 2 || (igemm2_mode() == 1 && wins);
+}
+
+template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI, int NBL>
+int launch2(const ConvArgs& a, hipStream_t st) {   // NOLINT
+  auto kern = igemm2_s2_kernel<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI, NBL>;
+  constexpr size_t smem = igemm2_smem<KIND, BN, TW, TH, NI, NBL>();
+  EAE_HIP(eae_smem_attr(reinterpret_cast<const void*>(kern), smem));
+  const int Hpos = (KIND == KIND_CONV) ? a.Hin / 2 : a.Hin, Wpos = (KIND == KIND_CONV) ? a.Win / 2 : a.Win;
+  const int groups = (a.B + NI - 1) / NI;
+  const int ntiles = groups * (Hpos / TH) * (Wpos / TW);
+  dim3 grid(ntiles * (NBL > 1 ? 1 : COUT / BN));
+  ConvArgs b = a;
+  b.ntiles = ntiles;
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, b);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+
 // EAE_IG_SMALL (bit mask, experiments): 1 = 64-position tiles for the conv kind on 8x8 / 4x4 output maps (twice the workgroups),
 // 2 = 32-channel blocks for the transposed kind on 8x8 / 4x4 input maps (twice the workgroups)
 static int ig_small() { static const int v = getenv("EAE_IG_SMALL") ? atoi(getenv("EAE_IG_SMALL")) : 0; return v; }
@@ -31,6 +60,11 @@ int conv_geo(const ConvArgs& a, hipStream_t st) {
   const int Hp = a.Hin / 2, Wp = a.Win / 2;
   if (Wp % 16 == 0 && Hp % 8 == 0) return launch<KIND_CONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st);
   if constexpr (CIN >= 64) {
+    constexpr int NBL = (CIN == 64) ? COUT / BN : 1;       // two chunks: both stay resident, the workgroup loops over the channel blocks
+    if (igemm2_on<KIND_CONV, CIN, EPI>() && !(ig_small() & 1)) {
+      if (Wp == 8 && Hp == 8) return launch2<KIND_CONV, CIN, COUT, BN, 8, 8, 2, SRC, EPI, NBL>(a, st);
+      if (Wp == 4 && Hp == 4) return launch2<KIND_CONV, CIN, COUT, BN, 4, 4, 8, SRC, EPI, NBL>(a, st);
+    }
     if (Wp == 8 && Hp == 8 && (ig_small() & 1)) return launch<KIND_CONV, CIN, COUT, BN, 8, 8, 1, SRC, EPI>(a, st);
     if (Wp == 4 && Hp == 4 && (ig_small() & 1)) return launch<KIND_CONV, CIN, COUT, BN, 4, 4, 4, SRC, EPI>(a, st);
   }
@@ -51,6 +85,12 @@ int deconv_geo(const ConvArgs& a, hipStream_t st) {
     if (a.Win % 16 == 0 && a.Hin % 4 == 0 && deconv64_th4()) return launch<KIND_DECONV, CIN, COUT, BN, 16, 4, 1, SRC, EPI>(a, st);
   }
   if (a.Win % 16 == 0 && a.Hin % 8 == 0) return launch<KIND_DECONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st);
+  if constexpr (CIN >= 128) {
+    if (igemm2_on<KIND_DECONV, CIN, EPI>()) {
+      if (a.Win == 8 && a.Hin == 8) return launch2<KIND_DECONV, CIN, COUT, BN, 8, 8, 1, SRC, EPI, 1>(a, st);
+      if (a.Win == 4 && a.Hin == 4) return launch2<KIND_DECONV, CIN, COUT, BN, 4, 4, 4, SRC, EPI, 1>(a, st);
+    }
+  }
   if (a.Win == 8 && a.Hin == 8) return launch<KIND_DECONV, CIN, COUT, BN, 8, 8, 1, SRC, EPI>(a, st);
   if (a.Win == 4 && a.Hin == 4) return launch<KIND_DECONV, CIN, COUT, BN, 4, 4, 4, SRC, EPI>(a, st);
   return eae_set_error(-2, "deconv_s2: unsupported spatial size (input must be 4x4, 8x8 or a multiple of 8x16)");

@@ -350,6 +350,9 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
 #pragma unroll
           for (int kx = 0; kx < G::NKX; ++kx) rf[(R + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(patch + lbase[kx] + (R + 1) * G::RS);
         }
+        // pin the order "fragments of row R+1 requested, then the MFMAs of row R": left alone, hipcc sinks the ds_read_b128 next to
+        // their MFMAs (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma: a full LDS round trip per MFMA, seen in the ISA of several instances)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int cx = 0; cx < G::NKX; ++cx)
 #pragma unroll
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
             const int mi = (R - ry) / G::MUL;
             acc[G::tap_phase(tap)][mi] = mfma16(wf[tap], rf[R & 1][cx], acc[G::tap_phase(tap)][mi]);
           }
+        __builtin_amdgcn_sched_barrier(0);
         if (chunk + 1 < NC && R < G::NOFF) issue_slice(chunk + 1, R);
       }
     } else {
@@ -374,12 +378,14 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
           for (int mi = 0; mi < MT; ++mi)
             pf[(o + 1) % PFB][mi] = *reinterpret_cast<const bf16x8*>(patch + lbase[G::off_col(o + 1)] + G::frag_const(mi, o + 1));
         }
+        if (PFB == 2) __builtin_amdgcn_sched_barrier(0);      // fragments of offset o+1 requested BEFORE the MFMAs of offset o (see above)
   #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           if (G::tap_off(tap) != o) continue;
   #pragma unroll
           for (int mi = 0; mi < MT; ++mi) acc[G::tap_phase(tap)][mi] = mfma16(wf[tap], pf[o % PFB][mi], acc[G::tap_phase(tap)][mi]);
         }
+        if (PFB == 2) __builtin_amdgcn_sched_barrier(0);
         if (PFB == 1 && o + 1 < G::NOFF) {
   #pragma unroll
           for (int mi = 0; mi < MT; ++mi)

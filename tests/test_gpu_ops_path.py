@@ -7,6 +7,7 @@ bf16 operands against the NumPy oracle (R.md:292-305 / 370-379 and their autogra
   * the map sizes the path uses (32/16/8/4 pixels: 16x8 tiles, 2 images per tile, 8 images per tile) with batch sizes that
     are NOT a multiple of the images-per-tile count.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -190,3 +191,15 @@ def test_wgrad_repeatable_and_slice_count_independent(lib):
         torch.cuda.synchronize()
         outs.append(dw.cpu().numpy().copy())
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_igemm_cases_with_every_layer_on_the_wave_specialised_kernel():
+    """The launcher reads EAE_IGEMM2 once per process (default: the wave-specialised kernel only where it wins inside the step), so
+    the cases above run again in ONE child process with EAE_IGEMM2=2 (every layer it is instantiated for) and with 0 (none)."""
+    import subprocess
+    import sys
+    for mode in ("2", "0"):
+        env = dict(os.environ, EAE_IGEMM2=mode)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "igemm and not every_layer",
+                            "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, f"EAE_IGEMM2={mode}\n" + r.stdout[-3000:] + r.stderr[-2000:]
