@@ -93,6 +93,8 @@ struct eae_ctx {
   // folded BatchNorm finalize (forward): fixed-point statistics accumulators per BN layer
   unsigned long long* accf[7] = {};
   int acc_copies[7] = {};
+  unsigned long long* accb[7] = {};      // BatchNorm-backward accumulators (same region and layout, behind the forward ones)
+  bool fold_bwd = true;
   uint8_t* acc_base = nullptr;
   size_t acc_bytes = 0;
   bool acc_clean = false;          // all zero (cleared by the engine's own Adam launch or at creation)
@@ -224,7 +226,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
       acc_total += (size_t)cp * 2 * BN_C[l] * 8;
     }
   }
-  size_t o_accb = carve(acc_total);      // conv1 weight gradient (last kernel of the backward, runs on the main stream)
+  size_t o_accb = carve(2 * acc_total);  // forward accumulators, then the backward ones (cleared together)   // conv1 weight gradient (last kernel of the backward, runs on the main stream)
   const int ksplit = (int)(c->K / 128);
   size_t o_fcp = carve((size_t)ksplit * Bm * c->L * 4);
   size_t o_mse = carve(std::max((size_t)eae_edge_tiles((int)Bm, c->H, c->W), (size_t)((Bm * c->H * c->W + 255) / 256)) * 4 * 4);
@@ -264,8 +266,9 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->z = (float*)(b + o_z); c->dz = (float*)(b + o_dz); c->dzc = (float*)(b + o_dzc);
   for (int l = 0; l < 7; ++l) { c->coef_f[l] = (float*)(b + o_cf[l]); c->coef_b[l] = (float*)(b + o_cb[l]); }
   c->stat = (float*)(b + o_stat); c->wscratch = (float*)(b + o_wscr); c->wscratch_main = (float*)(b + o_wscrm);
-  c->acc_base = b + o_accb; c->acc_bytes = (acc_total + 15) & ~(size_t)15;
+  c->acc_base = b + o_accb; c->acc_bytes = (2 * acc_total + 15) & ~(size_t)15;
   for (int l = 0; l < 7; ++l) c->accf[l] = (unsigned long long*)(b + o_accb + o_acc[l]);
+  for (int l = 0; l < 7; ++l) c->accb[l] = (unsigned long long*)(b + o_accb + acc_total + o_acc[l]);
   for (int i = 0; i < c->nx; ++i) c->wscratchx[i] = (float*)(b + o_wscrx[i]); c->fcpart = (float*)(b + o_fcp);
   c->msepart = (float*)(b + o_mse); c->cepart = (float*)(b + o_ce); c->headpart = (float*)(b + o_head); c->lossbuf = (float*)(b + o_loss);
   c->pack = b + o_pack; c->descs_dev = (PackDesc*)(b + o_desc);
@@ -281,6 +284,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   if (e == hipSuccess) e = hipMemset(c->sigwords, 0, 64);
   c->acc_clean = true;
   c->fold_fwd = getenv("EAE_NO_FOLD_FWD") == nullptr;
+  c->fold_bwd = getenv("EAE_NO_FOLD_BWD") == nullptr;
   if (e != hipSuccess) { hipFree(c->ws); delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
   c->use_side = getenv("EAE_NO_SIDE_STREAM") == nullptr;
   if (c->use_side) {
@@ -389,7 +393,10 @@ extern "C" int eae_set_sync_bn(eae_ctx* c, int world, eae_sync_fn fn, void* user
   if (!c->fold_fwd) return eae_set_error(EAE_ERR_STATE, "SyncBN needs the folded forward finalize (unset EAE_NO_FOLD_FWD)");
   // the forward accumulators move into the caller's buffer (same layout), so that the hook can hand tensor views of it to the collective
   uint8_t* nb = static_cast<uint8_t*>(acc_i64);
-  for (int l = 0; l < 7; ++l) c->accf[l] = reinterpret_cast<unsigned long long*>(nb + (reinterpret_cast<uint8_t*>(c->accf[l]) - c->acc_base));
+  for (int l = 0; l < 7; ++l) {
+    c->accf[l] = reinterpret_cast<unsigned long long*>(nb + (reinterpret_cast<uint8_t*>(c->accf[l]) - c->acc_base));
+    c->accb[l] = reinterpret_cast<unsigned long long*>(nb + (reinterpret_cast<uint8_t*>(c->accb[l]) - c->acc_base));
+  }
   c->acc_base = nb;
   c->acc_clean = false;
   c->sync_world = world; c->sync_fn = fn; c->sync_user = user; c->sync_sums = static_cast<double*>(sums_f64);
@@ -612,7 +619,27 @@ int bn_fwd_finalize(eae_ctx* c, hipStream_t st, int l, int ntiles, long long cou
   return eae_launch_bn_eval_coef(st, BN_C[l], gamma, beta, rm, rv, BN_EPS, c->coef_f[l]);
 }
 
+constexpr float ACC_SCALE_BWD = 4398046511104.f;   // 2^42 (eae_common.hip.h, BnBwdFold)
+bool bwd_folded(const eae_ctx* c, int l) { (void)l; return c->fold_bwd && c->sync_world <= 1; }
+int bwd_copies(const eae_ctx* c, int l) { return std::min(c->acc_copies[l], BN_FOLD_KB * (256 / BN_C[l])); }
+// producer side of the folded BatchNorm-backward finalize of layer l: call before launching the kernel whose epilogue takes the sums
+void fold_bwd_producer(eae_ctx* c, ConvArgs& a, int l) {
+  if (!bwd_folded(c, l)) return;
+  a.stat_part = nullptr;
+  a.bacc.acc = c->accb[l]; a.bacc.copies = bwd_copies(c, l); a.bacc.scale = ACC_SCALE_BWD;
+}
+// consumer side: the kernels that read layer l's (g, y) pair with SRC_BNBWD build A, B, Cc from the accumulators; `writer`: the
+// main-stream consumer, whose workgroup 0 also stores dgamma / dbeta and the table
+void fold_bwd_consumer(eae_ctx* c, BnBwdFold& f, int l, long long count, bool writer) {
+  f = BnBwdFold();
+  if (!bwd_folded(c, l)) return;
+  f.acc = c->accb[l]; f.copies = bwd_copies(c, l); f.inv_scale = 1.0f / ACC_SCALE_BWD; f.count = (float)count;
+  f.gamma = c->P + c->poff[BN_GAMMA_IDX[l]]; f.coef_fwd = c->coef_f[l];
+  if (writer) { f.dgamma = c->G + c->poff[BN_GAMMA_IDX[l]]; f.dbeta = c->G + c->poff[BN_GAMMA_IDX[l] + 1]; f.coef_out = c->coef_b[l]; }
+}
+
 int bn_bwd_fin(eae_ctx* c, hipStream_t st, int l, int ntiles, long long count) {
+  if (bwd_folded(c, l)) return 0;           // folded into the producer (accumulators) and its consumers (prologue)
   if (c->sync_world > 1) {
     double* sums = c->sync_sums + (size_t)l * 512;
     RC(eae_launch_bn_bwd_reduce(st, c->stat, ntiles, BN_C[l], sums, c->G + c->poff[BN_GAMMA_IDX[l]], c->G + c->poff[BN_GAMMA_IDX[l] + 1]));
@@ -824,6 +851,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
       a.c = ConvArgs();
       a.c.wpack = (const bf16_t*)(c->pack + c->pk_d4k); a.c.out = c->gu[2]; a.c.stat_part = c->stat;
       a.c.yprev = c->u[2]; a.c.prev_coef = c->coef_f[6]; a.c.B = B;
+      fold_bwd_producer(c, a.c, 6);
       take_sig(c, a.c);
       {
         ProfBracket pb(c, EAE_PROF_DECONV4_BWD, st);
@@ -842,6 +870,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
         w.small = (i == 0) ? src_raw(c->d0) : src_bnrelu(c->u[i - 1], c->coef_f[3 + i]);
         w.big = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
         w.B = B; w.Hs = Hs; w.Ws = Ws;
+        fold_bwd_consumer(c, w.bfold, 4 + i, (long long)B * (Hs * 2) * (Ws * 2), false);
         return eae_launch_wgrad_s2(s2, w, cs, cb, i == 0 ? SRC_RAW : SRC_BNRELU, SRC_BNBWD, scr, c->wscratch_floats, c->G + c->poff[20 + 4 * i],
                                    prof_hook_for(c, i == 2 ? EAE_PROF_DECONV3_WGRAD : -1));
       });
@@ -850,9 +879,11 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
       a.src = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
       a.wpack = (const bf16_t*)(c->pack + c->pk_p1[3 + i]);
       a.B = B; a.Hin = Hs * 2; a.Win = Ws * 2;
+      fold_bwd_consumer(c, a.bfold, 4 + i, (long long)B * a.Hin * a.Win, true);
       take_sig(c, a);
       if (i > 0) {
         a.out = c->gu[i - 1]; a.stat_part = c->stat; a.yprev = c->u[i - 1]; a.prev_coef = c->coef_f[3 + i];
+        fold_bwd_producer(c, a, 3 + i);
         {
           ProfBracket pb(c, i == 2 ? EAE_PROF_DECONV3_BWD : -1, st);
           RC(eae_launch_conv_s2(a, cb, cs, SRC_BNBWD, EPI_MASK, st));
@@ -907,6 +938,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     f.M = B; f.N = (int)c->K; f.K = c->L; f.klen = c->L;
     f.c = ConvArgs();
     f.c.out = c->gy[3]; f.c.stat_part = c->stat; f.c.yprev = c->y[3]; f.c.prev_coef = c->coef_f[3];
+    fold_bwd_producer(c, f.c, 3);
     take_sig(c, f.c);
     RC(eae_launch_fc_nt(st, f, SRC_F32, FCE_MASK, 1));
     RC(sq_commit(c, st));
@@ -922,6 +954,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
       w.small = src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
       w.big = src_bnrelu(c->y[i - 1], c->coef_f[i - 1]);
       w.B = B; w.Hs = Hs; w.Ws = Ws;
+      fold_bwd_consumer(c, w.bfold, i, (long long)B * Hs * Ws, false);
       return eae_launch_wgrad_s2(s2, w, cs, cb, SRC_BNBWD, SRC_BNRELU, scr, c->wscratch_floats, c->G + c->poff[4 * i],
                                  prof_hook_for(c, i == 1 ? EAE_PROF_CONV2_WGRAD : -1));
     });
@@ -931,6 +964,8 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     a.wpack = (const bf16_t*)(c->pack + c->pk_p2[i - 1]);
     a.out = c->gy[i - 1]; a.stat_part = c->stat; a.yprev = c->y[i - 1]; a.prev_coef = c->coef_f[i - 1];
     a.B = B; a.Hin = Hs; a.Win = Ws;
+    fold_bwd_producer(c, a, i - 1);
+    fold_bwd_consumer(c, a.bfold, i, (long long)B * Hs * Ws, true);
     take_sig(c, a);
     {
       ProfBracket pb(c, i == 1 ? EAE_PROF_CONV2_BWD : -1, st);
@@ -946,8 +981,10 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
   }
   // ---- conv1 weight gradient: nothing is left for the main stream to do, so the last weight gradient runs there (no fork
   //      latency in the tail of the step) while the side streams drain
+  BnBwdFold bf0;
+  fold_bwd_consumer(c, bf0, 0, (long long)B * (H / 2) * (W / 2), true);
   RC(eae_launch_edge_wgrad(st, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, c->wscratch_main,
-                           512LL * 864, c->G + c->poff[0], prof_hook_for(c, EAE_PROF_CONV1_WGRAD)));
+                           512LL * 864, c->G + c->poff[0], prof_hook_for(c, EAE_PROF_CONV1_WGRAD), &bf0));
   RC(join_side(c, st));
   // Biases in front of a BatchNorm have an identically zero gradient (the reference computes ~1e-9 rounding noise);
   // their slots in the gradient arena are zeroed once in eae_bind and never written.

@@ -179,20 +179,27 @@ __device__ __forceinline__ void bn_acc_add(const BnAcc& b, int C, int tile_id, i
 // issue order: a prologue whose loads queue behind the patch loads would wait for all of them) and CONSUMED after those are in
 // flight.  copies <= 4 * (256 / C)  (at most 4 accumulator sets per thread).
 constexpr int BN_FOLD_K = 4;
-struct BnFoldRegs { long long v[2][BN_FOLD_K]; };
+constexpr int BN_FOLD_KB = 2;      // backward tables: the consumers hold two source tensors' raw pieces in registers meanwhile
+template <int K> struct BnFoldRegsT { long long v[2][K]; };
+typedef BnFoldRegsT<BN_FOLD_K> BnFoldRegs;
+typedef BnFoldRegsT<BN_FOLD_KB> BnFoldRegsB;
 // `tid` = index of the calling thread among the 256 threads that build the table (default: the whole 256-thread workgroup)
-template <int C>
-__device__ __forceinline__ void bn_fold_load(const BnFold& f, BnFoldRegs& r, int tid = threadIdx.x) {
+template <int C, int K>
+__device__ __forceinline__ void bn_fold_load_acc(const unsigned long long* acc, int copies, BnFoldRegsT<K>& r, int tid) {
   static_assert(C <= 256 && 256 % C == 0, "channel count");
   constexpr int G = 256 / C;
   const int ch = tid % C, grp = tid / C;
 #pragma unroll
-  for (int j = 0; j < BN_FOLD_K; ++j) {
+  for (int j = 0; j < K; ++j) {
     const int k = grp + j * G;
-    const bool ok = k < f.copies;
-    r.v[0][j] = ok ? (long long)f.acc[((size_t)k * 2 + 0) * C + ch] : 0;
-    r.v[1][j] = ok ? (long long)f.acc[((size_t)k * 2 + 1) * C + ch] : 0;
+    const bool ok = k < copies;
+    r.v[0][j] = ok ? (long long)acc[((size_t)k * 2 + 0) * C + ch] : 0;
+    r.v[1][j] = ok ? (long long)acc[((size_t)k * 2 + 1) * C + ch] : 0;
   }
+}
+template <int C>
+__device__ __forceinline__ void bn_fold_load(const BnFold& f, BnFoldRegs& r, int tid = threadIdx.x) {
+  bn_fold_load_acc<C, BN_FOLD_K>(f.acc, f.copies, r, tid);
 }
 // All 256 threads of the workgroup.  table = LDS float [4][C]; red = LDS long long [2][256] (may alias any idle buffer).
 // (contains two workgroup barriers: every wave of the workgroup has to pass them, table builders or not)
@@ -234,6 +241,59 @@ __device__ __forceinline__ void bn_fold_fwd(const BnFold& f, float* table, long 
   BnFoldRegs r;
   bn_fold_load<C>(f, r);
   bn_fold_fwd_finish<C>(f, r, table, red, writer);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm BACKWARD finalize without a kernel of its own (the 7 finalize launches were 6.2 us each on the dependency chain),
+// same scheme as the forward one: the producer (the kernel whose epilogue applies the ReLU mask and takes sum g, sum g*xhat)
+// adds its workgroup sums in fixed point to [copies][2][C] integer accumulators; EVERY consumer workgroup (backward-data kernel
+// on the main stream, weight-gradient kernel on a side stream) sums the copies in its prologue, behind its own first loads, and
+// builds the table [3][C] = A, B, Cc of bn_bwd_finalize_kernel in LDS.  Workgroup 0 of the main-stream consumer also stores
+// dgamma / dbeta (and the table, for the per-op entry points and the diagnostics).  Integer sums: independent of the arrival
+// order, so bitwise reproducible.  2^42 fixed point: workgroup sums from 2.3e-13 to 2e6 in magnitude (beyond: NaN).
+// (A "last workgroup of the producer finalizes" variant was measured first: waiting for the atomics' return values and drawing a
+// ticket cost every producer workgroup two device-scope round trips at its end: 0.558 vs 0.5225 ms per step.)
+// ---------------------------------------------------------------------------------------------------------------
+struct BnBwdFold {
+  const unsigned long long* acc;   // nullptr: the coefficients come from SrcDesc::coef (bn_bwd_finalize_kernel wrote them)
+  int copies;
+  float inv_scale, count;
+  const float* gamma; const float* coef_fwd;       // [C], [4][C]
+  float* dgamma; float* dbeta; float* coef_out;    // [C], [C], [3][C]: written by the `writer` workgroup (each may be nullptr)
+};
+template <int C>
+__device__ __forceinline__ void bn_fold_bwd_load(const BnBwdFold& f, BnFoldRegsB& r, int tid = threadIdx.x) {
+  bn_fold_load_acc<C, BN_FOLD_KB>(f.acc, f.copies, r, tid);     // copies <= BN_FOLD_KB * (256 / C)
+}
+// 256 threads (tid 0..255).  table = LDS float [3][C]; red = LDS long long [2][256] (may alias any idle buffer).  Two barriers.
+template <int C>
+__device__ __forceinline__ void bn_fold_bwd_finish(const BnBwdFold& f, const BnFoldRegsB& r, float* table, long long* red, bool writer,
+                                                   int tid = threadIdx.x) {
+  constexpr int G = 256 / C;
+  const int ch = tid % C, grp = tid / C;
+  long long s1 = 0, s2 = 0;
+#pragma unroll
+  for (int j = 0; j < BN_FOLD_KB; ++j) { s1 += r.v[0][j]; s2 += r.v[1][j]; }
+  red[tid] = s1; red[256 + tid] = s2;
+  __syncthreads();
+  if (grp == 0) {
+#pragma unroll
+    for (int g = 1; g < G; ++g) { s1 += red[g * C + ch]; s2 += red[256 + g * C + ch]; }
+    const bool poisoned = s1 >= (BN_ACC_POISON >> 1) || s1 <= -(BN_ACC_POISON >> 1) || s2 >= (BN_ACC_POISON >> 1) || s2 <= -(BN_ACC_POISON >> 1);
+    const float db = poisoned ? __builtin_nanf("") : (float)((double)s1 * (double)f.inv_scale);
+    const float dg = (float)((double)s2 * (double)f.inv_scale);
+    const float mean = f.coef_fwd[2 * C + ch], invstd = f.coef_fwd[3 * C + ch];
+    const float A = f.gamma[ch] * invstd;
+    const float Bc = -A * invstd * dg / f.count;
+    const float Cc = -A * db / f.count - Bc * mean;
+    table[ch] = A; table[C + ch] = Bc; table[2 * C + ch] = Cc;
+    if (writer) {
+      if (f.dbeta) f.dbeta[ch] = db;
+      if (f.dgamma) f.dgamma[ch] = dg;
+      if (f.coef_out) { f.coef_out[ch] = A; f.coef_out[C + ch] = Bc; f.coef_out[2 * C + ch] = Cc; }
+    }
+  }
+  __syncthreads();
 }
 
 // first thread of the grid publishes the stream's progress value (relaxed agent-scope store: bypasses the non-coherent caches)

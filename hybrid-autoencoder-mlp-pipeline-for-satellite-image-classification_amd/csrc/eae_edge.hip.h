@@ -173,6 +173,7 @@ struct EdgeWgradArgs {
   SrcDesc side;           // [B,H/2,W/2,32] tensor with its load transform
   float* part;            // [nblocks][32*27]
   int tiles_per_block, ntiles;
+  BnBwdFold bfold;        // SRC_BNBWD side: coefficient table from the layer's backward accumulators (eae_common.hip.h)
 };
 
 template <int SRC3, int SMODE>
@@ -180,13 +181,23 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(EdgeWgradArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t p3[E_PATCH];
   __shared__ __attribute__((aligned(16))) bf16_t at[E_AT];
   __shared__ __attribute__((aligned(16))) bf16_t st[E_AT];
-  __shared__ float racc[4][2][2][64 * 4];
+  __shared__ __attribute__((aligned(16))) float racc[4][2][2][64 * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Hout = a.H >> 1, Wout = a.W >> 1;
   const int tiles_x = Wout / E_TW, tiles_y = Hout / E_TH;
   const int kgs = tid & 3;
   ChanCoef<SMODE> cc;
-  cc.load(a.side.coef, 32, kgs * 8);
+  {
+    __shared__ float coef_tab[SMODE == SRC_BNBWD ? 3 * 32 : 4];
+    const float* coefp = a.side.coef;
+    if (SMODE == SRC_BNBWD && a.bfold.acc != nullptr) {      // folded BatchNorm-backward finalize (this kernel is the layer's only consumer)
+      BnFoldRegsB fr;
+      bn_fold_bwd_load<32>(a.bfold, fr);
+      bn_fold_bwd_finish<32>(a.bfold, fr, coef_tab, reinterpret_cast<long long*>(&racc[0][0][0][0]), blockIdx.x == 0);
+      coefp = coef_tab;
+    }
+    cc.load(coefp, 32, kgs * 8);
+  }
   f32x4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)

@@ -26,9 +26,10 @@ int eae_edge_tiles(int B, int H, int W) { return B * (H / 2 / E_TH) * (W / 2 / E
 
 // dw [32][3][3][3] = reduce over blocks of the per-block partials. scratch must hold nblocks*864 floats.
 int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B, int H, int W, const SrcDesc& side, int smode,
-                          float* scratch, long long scratch_floats, float* dw, const EaeProfHook* hook) {
+                          float* scratch, long long scratch_floats, float* dw, const EaeProfHook* hook, const BnBwdFold* bfold) {
   if (int rc = check_edge_shape(B, H, W)) return rc;
   EdgeWgradArgs a;
+  a.bfold = bfold ? *bfold : BnBwdFold();
   a.src3 = src3; a.B = B; a.H = H; a.W = W; a.side = side; a.part = scratch;
   a.ntiles = eae_edge_tiles(B, H, W);
   int nblocks = a.ntiles < 512 ? a.ntiles : 512;

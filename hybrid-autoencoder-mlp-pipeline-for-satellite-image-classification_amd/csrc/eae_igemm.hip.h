@@ -39,6 +39,7 @@ struct ConvArgs {
   unsigned sig_val;
   BnAcc bacc;              // statistics go to fixed-point accumulators instead of stat_part (finalize folded into the consumer)
   BnFold fold;             // SRC_BNRELU: build the source layer's coefficient table from its accumulators
+  BnBwdFold bfold;         // SRC_BNBWD: build the source layer's backward coefficient table from its accumulators
 #ifdef EAE_STAMPS
   unsigned long long* dbg; // diagnostic build only: s_memtime stamps of workgroup `dbg_block`, wave 0
   int dbg_block;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
   ChanCoef<SRC> cc;
   // prefetch requests are issued in NOFF slices, one after each offset's MFMA group, so that the vector-memory pipe
   // (the 64 B/clk L1 path is the scarce resource of the multi-chunk layers) drains while the matrix pipe works
-  __shared__ float coef_tab[(SRC == SRC_BNRELU) ? 4 * CIN : 4];
+  __shared__ float coef_tab[(SRC == SRC_BNRELU) ? 4 * CIN : (SRC == SRC_BNBWD) ? 3 * CIN : 4];
   const float* coefp = a.src.coef;
   auto issue_slice = [&](int chunk, int o, bool with_coef = true) {
     if (o == 0 && with_coef) cc.load(coefp, CIN, chunk * 32 + kgs * 8);
@@ -310,14 +311,24 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
   };
   // accumulator loads first, then the first chunk's weight / patch loads: the table is built while those are in flight
   BnFoldRegs fr;
+  BnFoldRegsB frb;
   const bool folded = SRC == SRC_BNRELU && a.fold.acc != nullptr;
+  const bool folded_b = SRC == SRC_BNBWD && a.bfold.acc != nullptr;
   if (folded) bn_fold_load<CIN>(a.fold, fr);
-  load_w(0);
+  if (folded_b) bn_fold_bwd_load<CIN>(a.bfold, frb);
+  if (SRC != SRC_BNBWD) load_w(0);
   issue(0, false);
   if (folded) {
     bn_fold_fwd_finish<CIN>(a.fold, fr, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0);
     coefp = coef_tab;
   }
+  if (folded_b) {
+    bn_fold_bwd_finish<CIN>(a.bfold, frb, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0);
+    coefp = coef_tab;
+  }
+  // two source tensors' raw pieces are in registers while the table is built: the weight fragments (L2-resident, needed only at
+  // the first MFMA) are requested behind it, or the builder's temporaries spill
+  if (SRC == SRC_BNBWD) load_w(0);
   cc.load(coefp, CIN, kgs * 8);
 #pragma unroll
   for (int chunk = 0; chunk < NC; ++chunk) {

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   static_assert(NBL == 1 || (NBL == NB && NC == 2), "the channel-block loop needs every chunk resident in the two patch buffers");
   static_assert(TH * TW <= 16 || (TH % (MT * G::RPM) == 0) || (WM == 1 && (MT * G::RPM) % TH == 0), "m-tile rows must not straddle images");
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-  __shared__ float coef_tab[(SRC == SRC_BNRELU) ? 4 * CIN : 4];
+  __shared__ float coef_tab[(SRC == SRC_BNRELU) ? 4 * CIN : (SRC == SRC_BNBWD) ? 3 * CIN : 4];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0-3 consumers, 4-7 producers
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int img0 = t * NI;
   const int iy0 = (KIND == KIND_CONV) ? 2 * tyb * TH - 1 : tyb * TH, ix0 = (KIND == KIND_CONV) ? 2 * txb * TW - 1 : txb * TW;
   const bool folded = SRC == SRC_BNRELU && a.fold.acc != nullptr;
+  const bool folded_b = SRC == SRC_BNBWD && a.bfold.acc != nullptr;
   bf16_t* const patch0 = smem;
   bf16_t* const patch1 = smem + PATCH;
 
@@ -107,11 +108,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           *reinterpret_cast<uint4*>(patch + loff[i]) = transform_piece<SRC>(r[i], val[i], cc);
     };
     BnFoldRegs fr;
+    BnFoldRegsB frb;
     if (folded) bn_fold_load<CIN>(a.fold, fr, ptid);      // accumulator loads first: vector-memory results return in issue order
+    if (folded_b) bn_fold_bwd_load<CIN>(a.bfold, frb, ptid);
     issue(0, ra);
     issue(1, rb);
     if (folded) {
       bn_fold_fwd_finish<CIN>(a.fold, fr, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0, ptid);   // two barriers
+      coefp = coef_tab;
+    }
+    if (folded_b) {
+      bn_fold_bwd_finish<CIN>(a.bfold, frb, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0, ptid);  // two barriers
       coefp = coef_tab;
     }
     stage(0, ra, patch0);
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     load_w(0, wfa);
     load_w(1, wfb);
     if (nbi == 0) {
-      if (folded) { __syncthreads(); __syncthreads(); }    // the producers' coefficient-table barriers
+      if (folded || folded_b) { __syncthreads(); __syncthreads(); }    // the producers' coefficient-table barriers
       __syncthreads();                                     // chunk 0 staged
     }
 #pragma unroll

@@ -35,6 +35,7 @@ struct WgradArgs {
   float* part;            // [nslices][CS][CB][9]
   int B, Hs, Ws;          // small-map spatial size (big map = 2Hs x 2Ws)
   int tiles_per_block, ntiles, nslices;
+  BnBwdFold bfold;        // the SRC_BNBWD operand's coefficient table from the layer's backward accumulators (eae_common.hip.h)
 };
 
 constexpr int S_STRIDE = 72;   // bf16 elements per staged S row: 64 channels + 8 pad (144 B)
@@ -87,6 +88,12 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_s2_kernel(WgradArgs a) {
   bf16_t* buf0 = smem;
   bf16_t* buf1 = smem + G::BUF_ELEMS;
   float* ep = reinterpret_cast<float*>(smem);                   // epilogue image, aliases the tile buffers
+  // folded BatchNorm-backward finalize: the consumer waves (idle until the first tile is staged) build the table of the
+  // SRC_BNBWD operand while the producers' first loads are in flight
+  constexpr bool HASB = SMODE == SRC_BNBWD || BMODE == SRC_BNBWD;
+  constexpr int CX = (SMODE == SRC_BNBWD) ? CS : CB;
+  __shared__ float coef_tab[HASB ? 3 * CX : 4];
+  const bool folded_b = HASB && a.bfold.acc != nullptr;
 
   if (wave >= 4) {
     // ================================================================ producers (512 threads)
@@ -95,9 +102,9 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_s2_kernel(WgradArgs a) {
     const int tiles_x = a.Ws / TW, tiles_y = a.Hs / TH;
     const int kgs4 = tid & 3, kgs8 = tid & 7;
     ChanCoef<BMODE> ccb;
-    ccb.load(a.big.coef, CB, cb0 + kgs4 * 8);
     ChanCoef<SMODE> ccs;
-    ccs.load(a.small.coef, CS, cs0 + kgs8 * 8);
+    if (!(folded_b && BMODE == SRC_BNBWD)) ccb.load(a.big.coef, CB, cb0 + kgs4 * 8);
+    if (!(folded_b && SMODE == SRC_BNBWD)) ccs.load(a.small.coef, CS, cs0 + kgs8 * 8);
     SrcRsrc rsb, rss;
     rsb.init<BMODE>(a.big);
     rss.init<SMODE>(a.small);
@@ -151,6 +158,13 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_s2_kernel(WgradArgs a) {
     if (n > 0) {
       issue(ra, t_first);
       if (n > 1) issue(rb, t_first + 1);
+    }
+    if (folded_b) {
+      __syncthreads(); __syncthreads();               // the consumers' coefficient-table barriers
+      if (BMODE == SRC_BNBWD) ccb.load(coef_tab, CB, cb0 + kgs4 * 8);
+      if (SMODE == SRC_BNBWD) ccs.load(coef_tab, CS, cs0 + kgs8 * 8);
+    }
+    if (n > 0) {
       stage(ra, buf0);
       if (n > 2) issue(ra, t_first + 2);
     }
@@ -167,6 +181,11 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_s2_kernel(WgradArgs a) {
     __syncthreads();                                  // consumers have written the epilogue image
   } else {
     // ================================================================ consumers (256 threads)
+    if (folded_b) {
+      BnFoldRegsB fr;
+      bn_fold_bwd_load<CX>(a.bfold, fr);
+      bn_fold_bwd_finish<CX>(a.bfold, fr, coef_tab, reinterpret_cast<long long*>(smem), false);      // two barriers
+    }
     const int it0 = 2 * (wave & 1), jt = wave >> 1;
     f32x4 acc[9][2];
 #pragma unroll
