@@ -50,9 +50,21 @@ int launch2(const ConvArgs& a, hipStream_t st) {   // NOLINT
   return 0;
 }
 
-// EAE_IG_SMALL (bit mask, experiments): 1 = 64-position tiles for the conv kind on 8x8 / 4x4 output maps (twice the workgroups),
-// 2 = 32-channel blocks for the transposed kind on 8x8 / 4x4 input maps (twice the workgroups)
-static int ig_small() { static const int v = getenv("EAE_IG_SMALL") ? atoi(getenv("EAE_IG_SMALL")) : 0; return v; }
+// Small-tile geometries for the 8x8 / 4x4 maps: 64-position tiles for the conv kind, 32-channel blocks for the transposed kind --
+// twice the workgroups, each with half the work.  They pay when the 128-position grid leaves most of the 256 CUs empty (ms per step,
+// small vs large: B=64 0.255 vs 0.280, B=128 0.288 vs 0.310, B=256 0.369 vs 0.371) and lose at B=512, so a layer takes them when its
+// large-tile grid has fewer than 256 workgroups.  EAE_IG_SMALL=<mask> overrides (bit 0: conv kind, bit 1: transposed kind).
+static int ig_small_env() { static const int v = getenv("EAE_IG_SMALL") ? atoi(getenv("EAE_IG_SMALL")) : -1; return v; }
+static bool conv_small(int B, int Wp, int cout) {
+  if (ig_small_env() >= 0) return (ig_small_env() & 1) != 0;
+  const int nt = (Wp == 8) ? (B + 1) / 2 : (B + 7) / 8;
+  return nt * (cout / 64) < 256;
+}
+static bool deconv_small(int B, int Win, int cout) {
+  if (ig_small_env() >= 0) return (ig_small_env() & 2) != 0;
+  const int nt = (Win == 8) ? B : (B + 3) / 4;
+  return nt * (cout / 64) < 256;
+}
 
 // geometry by the size of the position grid (conv: output map; deconv: input map)
 template <int CIN, int COUT, int BN, int SRC, int EPI>
@@ -61,12 +73,13 @@ int conv_geo(const ConvArgs& a, hipStream_t st) {
   if (Wp % 16 == 0 && Hp % 8 == 0) return launch<KIND_CONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st);
   if constexpr (CIN >= 64) {
     constexpr int NBL = (CIN == 64) ? COUT / BN : 1;       // two chunks: both stay resident, the workgroup loops over the channel blocks
-    if (igemm2_on<KIND_CONV, CIN, EPI>() && !(ig_small() & 1)) {
+    const bool small = (Wp == 8 || Wp == 4) && conv_small(a.B, Wp, COUT);
+    if (igemm2_on<KIND_CONV, CIN, EPI>() && !small) {
       if (Wp == 8 && Hp == 8) return launch2<KIND_CONV, CIN, COUT, BN, 8, 8, 2, SRC, EPI, NBL>(a, st);
       if (Wp == 4 && Hp == 4) return launch2<KIND_CONV, CIN, COUT, BN, 4, 4, 8, SRC, EPI, NBL>(a, st);
     }
-    if (Wp == 8 && Hp == 8 && (ig_small() & 1)) return launch<KIND_CONV, CIN, COUT, BN, 8, 8, 1, SRC, EPI>(a, st);
-    if (Wp == 4 && Hp == 4 && (ig_small() & 1)) return launch<KIND_CONV, CIN, COUT, BN, 4, 4, 4, SRC, EPI>(a, st);
+    if (Wp == 8 && Hp == 8 && small) return launch<KIND_CONV, CIN, COUT, BN, 8, 8, 1, SRC, EPI>(a, st);
+    if (Wp == 4 && Hp == 4 && small) return launch<KIND_CONV, CIN, COUT, BN, 4, 4, 4, SRC, EPI>(a, st);
   }
   if (Wp == 8 && Hp == 8) return launch<KIND_CONV, CIN, COUT, BN, 8, 8, 2, SRC, EPI>(a, st);
   if (Wp == 4 && Hp == 4) return launch<KIND_CONV, CIN, COUT, BN, 4, 4, 8, SRC, EPI>(a, st);
@@ -122,7 +135,7 @@ int eae_launch_conv_s2(const ConvArgs& a, int cin, int cout, int src, int epi, h
 int eae_launch_deconv_s2(const ConvArgs& a, int cin, int cout, int src, int epi, hipStream_t st) {
   if (a.B <= 0) return eae_set_error(-2, "deconv_s2: bad shape");
 #define CASE(CI, CO, BN_, S, E) if (cin == CI && cout == CO && src == S && epi == E) return deconv_geo<CI, CO, BN_, S, E>(a, st)
-  if ((ig_small() & 2) && a.Win <= 8) {
+  if ((a.Win == 8 || a.Win == 4) && a.Hin == a.Win && cout >= 64 && deconv_small(a.B, a.Win, cout)) {
     CASE(256, 128, 32, SRC_RAW, EPI_FWD);
     CASE(128, 64, 32, SRC_BNRELU, EPI_FWD);
     CASE(256, 128, 32, SRC_BNBWD, EPI_MASK);
@@ -145,9 +158,9 @@ int eae_conv_s2_ntiles(int kind, int B, int Hin, int Win, int cin) {
   if (kind == 0) {
     int Hp = Hin / 2, Wp = Win / 2;
     if (Wp % 16 == 0 && Hp % 8 == 0) return B * (Hp / 8) * (Wp / 16);
-    if (cin >= 64 && (ig_small() & 1)) {
-      if (Wp == 8 && Hp == 8) return B;
-      if (Wp == 4 && Hp == 4) return (B + 3) / 4;
+    if (cin >= 64 && Wp == Hp && (Wp == 8 || Wp == 4) && conv_small(B, Wp, 2 * cin)) {      // (every instantiated conv layer doubles the channels)
+      if (Wp == 8) return B;
+      return (B + 3) / 4;
     }
     if (Wp == 8 && Hp == 8) return (B + 1) / 2;
     if (Wp == 4 && Hp == 4) return (B + 7) / 8;

@@ -194,26 +194,29 @@ int eae_launch_signal(hipStream_t st, unsigned* word, unsigned val) {
 // ---------------------------------------------------------------------------------------------------------------
 // Weight packing: one launch converts every fp32 master weight into the bf16 layouts the kernels read.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float pack_fetch(const PackDesc& d, const float* __restrict__ src, long i) {
+// (32-bit unsigned index arithmetic: destination and source element counts stay below 2^32, and a 64-bit division costs ~5x a
+// 32-bit one on this target -- the all-64-bit version of this kernel took 14 us per step)
+__device__ __forceinline__ float pack_fetch(const PackDesc& d, const float* __restrict__ src, unsigned i) {
+  const unsigned d0 = (unsigned)d.d0, d1 = (unsigned)d.d1, d2 = (unsigned)d.d2;
   switch (d.mode) {
     case PACK_3x3_P1: {   // dst [A][9][B]  <- src [A][B][3][3]
-      int b = i % d.d1; long r = i / d.d1; int tap = r % 9; int a = r / 9;
-      return src[((long)a * d.d1 + b) * 9 + tap];
+      unsigned b = i % d1, r = i / d1, tap = r % 9u, a = r / 9u;
+      return src[(a * d1 + b) * 9u + tap];
     }
     case PACK_3x3_P2: {   // dst [B][9][A]  <- src [A][B][3][3]
-      int a = i % d.d0; long r = i / d.d0; int tap = r % 9; int b = r / 9;
-      return src[((long)a * d.d1 + b) * 9 + tap];
+      unsigned a = i % d0, r = i / d0, tap = r % 9u, b = r / 9u;
+      return src[(a * d1 + b) * 9u + tap];
     }
     case PACK_K27: {      // dst [A][32] with k = tap*3 + c (zero for k >= 27)  <- src [A][3][3][3]
-      int k = i & 31; int a = i >> 5;
-      if (k >= 27) return 0.f;
-      int tap = k / 3, c = k % 3;
-      return src[((long)a * 3 + c) * 9 + tap];
+      unsigned k = i & 31u, a = i >> 5;
+      if (k >= 27u) return 0.f;
+      unsigned tap = k / 3u, c = k % 3u;
+      return src[(a * 3u + c) * 9u + tap];
     }
     case PACK_K36: {      // dst [A][64] with k = tap*4 + c (zero for c == 3 and k >= 36)  <- src [A][3][3][3]   (edge_conv_kernel)
-      int k = i & 63; int a = i >> 6;
-      if (k >= 36 || (k & 3) == 3) return 0.f;
-      return src[((long)a * 3 + (k & 3)) * 9 + (k >> 2)];
+      unsigned k = i & 63u, a = i >> 6;
+      if (k >= 36u || (k & 3u) == 3u) return 0.f;
+      return src[(a * 3u + (k & 3u)) * 9u + (k >> 2)];
     }
     case PACK_DECONV4_JOINT: {   // dst [16][128]: n = phase*3+co, k = nb*32+ci  <- src [32 ci][3 co][3][3]
       int k = i & 127; int n = i >> 7;
@@ -223,28 +226,27 @@ __device__ __forceinline__ float pack_fetch(const PackDesc& d, const float* __re
       int ky = py == 0 ? (dy == 0 ? 1 : -1) : (dy == 0 ? 2 : 0);
       int kx = px == 0 ? (dx == 0 ? 1 : -1) : (dx == 0 ? 2 : 0);
       if (ky < 0 || kx < 0) return 0.f;
-      return src[((long)ci * 3 + co) * 9 + ky * 3 + kx];
+      return src[(ci * 3 + co) * 9 + ky * 3 + kx];
     }
     case PACK_FC_ROWMAJOR_KPERM: {   // dst [R][K'] with k' = p*Cc + c  <- src [R][K] with k = c*P + p   (d0=R, d1=Cc, d2=P)
-      long K = (long)d.d1 * d.d2; long k2 = i % K; int r = i / K;
-      int c = k2 % d.d1, p = k2 / d.d1;
-      return src[(long)r * K + (long)c * d.d2 + p];
+      unsigned K = d1 * d2, k2 = i % K, r = i / K;
+      unsigned c = k2 % d1, p = k2 / d1;
+      return src[r * K + c * d2 + p];
     }
     case PACK_FC_TRANS_KPERM: {      // dst [K'][R]  <- src [R][K]   (transpose + permute)
-      int r = i % d.d0; long k2 = i / d.d0;
-      long K = (long)d.d1 * d.d2;
-      int c = k2 % d.d1, p = k2 / d.d1;
-      return src[(long)r * K + (long)c * d.d2 + p];
+      unsigned r = i % d0, k2 = i / d0, K = d1 * d2;
+      unsigned c = k2 % d1, p = k2 / d1;
+      return src[r * K + c * d2 + p];
     }
     case PACK_FC_ROWPERM: {          // dst [J'][L] with j' = p*Cc + c <- src [J][L] with j = c*P + p   (d0=L, d1=Cc, d2=P)
-      int l = i % d.d0; long j2 = i / d.d0;
-      int c = j2 % d.d1, p = j2 / d.d1;
-      return src[((long)c * d.d2 + p) * d.d0 + l];
+      unsigned l = i % d0, j2 = i / d0;
+      unsigned c = j2 % d1, p = j2 / d1;
+      return src[(c * d2 + p) * d0 + l];
     }
     case PACK_FC_ROWPERM_TRANS: {    // dst [L][J']  <- src [J][L]
-      long J = (long)d.d1 * d.d2; long j2 = i % J; int l = i / J;
-      int c = j2 % d.d1, p = j2 / d.d1;
-      return src[((long)c * d.d2 + p) * d.d0 + l];
+      unsigned J = d1 * d2, j2 = i % J, l = i / J;
+      unsigned c = j2 % d1, p = j2 / d1;
+      return src[(c * d2 + p) * d0 + l];
     }
     default: return src[i];          // PACK_COPY
   }
@@ -254,7 +256,8 @@ __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc*
                                                         uint8_t* __restrict__ pack_base) {
   const PackDesc d = descs[blockIdx.y];
   const float* src = params + d.src_off;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < d.count; i += (long)gridDim.x * 256) {
+  const unsigned count = (unsigned)d.count;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
     float v = pack_fetch(d, src, i);
     if (d.out_f32) reinterpret_cast<float*>(pack_base + d.dst_off)[i] = v;
     else reinterpret_cast<bf16_t*>(pack_base + d.dst_off)[i] = (bf16_t)f2bf(v);
@@ -262,7 +265,7 @@ __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc*
 }
 
 int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base) {
-  hipLaunchKernelGGL(pack_all_kernel, dim3(128, ndesc), dim3(256), 0, st, descs_dev, params, (uint8_t*)pack_base);
+  hipLaunchKernelGGL(pack_all_kernel, dim3(256, ndesc), dim3(256), 0, st, descs_dev, params, (uint8_t*)pack_base);
   EAE_LAUNCH_CHECK();
   return 0;
 }

@@ -201,9 +201,11 @@ def test_adam_trajectory_vs_golden(golden, tag, head):
         losses.append(float(eng.loss_last.cpu().numpy()[0]))
     # Adam's sign-like first steps at lr=5e-3 make the trajectory chaotic: the NumPy oracle with bf16 storage emulation
     # itself drifts from the fp32 golden by 0.2 % / 0.2 % / 0.9 % / 5.7 % over steps 2..5 (measured), so the bound
-    # widens with the step index.
+    # widens with the step index.  (Two builds of this engine that differ only in a tile geometry, i.e. in fp32 summation
+    # order, measured 1.8 % at step 4 and 9 % / 12 % at step 5.)
     np.testing.assert_allclose(np.array(losses)[:3], g["losses"][:3], rtol=1e-2)
-    np.testing.assert_allclose(np.array(losses), g["losses"], rtol=0.12)
+    np.testing.assert_allclose(np.array(losses)[3], g["losses"][3], rtol=5e-2)
+    np.testing.assert_allclose(np.array(losses)[4], g["losses"][4], rtol=0.2)
     sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     assert int(sd["enc.encoder.1.num_batches_tracked"]) == 5
     # final/* weights and BatchNorm buffers of the reference after the 5 steps.  Every step moves a weight by about +-lr, so two
@@ -218,8 +220,10 @@ def test_adam_trajectory_vs_golden(golden, tag, head):
         d, s = gu.tensor_digest(sd[name])
         if name.endswith("num_batches_tracked"):
             ok = int(sd[name]) == 5
-        elif "running" in name:            # measured: mean |d| <= 0.11, var <= 12 % of its max (8x8x8 samples per channel at b=8)
-            ok = np.abs(s - smp).max() <= 0.15 * np.abs(smp).max() + 0.12
+        elif "running" in name:            # measured: mean |d| <= 0.11, var <= 12 % of its max (8x8x8 samples per channel at b=8);
+            # 19 % on single channels of one layer with another tile geometry (the trajectory is chaotic, see above): the
+            # per-channel bound is loose, the norm of the whole buffer is held to 5 %
+            ok = np.abs(s - smp).max() <= 0.25 * np.abs(smp).max() + 0.12 and 0.95 <= d[1] / max(dg[1], 1e-30) <= 1.05
         elif gu.is_prebn_bias(name) or (not head and name.startswith("classifier")):
             ok = True                      # zero-gradient biases: the reference random-walks them, the engine keeps them
         else:

@@ -193,13 +193,15 @@ def test_wgrad_repeatable_and_slice_count_independent(lib):
     assert np.array_equal(outs[0], outs[1])
 
 
-def test_igemm_cases_with_every_layer_on_the_wave_specialised_kernel():
-    """The launcher reads EAE_IGEMM2 once per process (default: the wave-specialised kernel only where it wins inside the step), so
-    the cases above run again in ONE child process with EAE_IGEMM2=2 (every layer it is instantiated for) and with 0 (none)."""
+def test_igemm_cases_on_the_large_tile_geometries_and_the_wave_specialised_kernel():
+    """The launcher picks the geometry from the grid size (small batches, like the cases above: 64-position tiles / 32-channel
+    blocks) and reads EAE_IGEMM2 / EAE_IG_SMALL once per process.  The cases above therefore run again in ONE child process per
+    setting: large tiles (EAE_IG_SMALL=0, what B=512 uses) with the wave-specialised kernel on every layer it is instantiated
+    for (EAE_IGEMM2=2) and on none (0)."""
     import subprocess
     import sys
     for mode in ("2", "0"):
-        env = dict(os.environ, EAE_IGEMM2=mode)
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "igemm and not every_layer",
+        env = dict(os.environ, EAE_IGEMM2=mode, EAE_IG_SMALL="0")
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "igemm_instantiation",
                             "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, f"EAE_IGEMM2={mode}\n" + r.stdout[-3000:] + r.stderr[-2000:]
