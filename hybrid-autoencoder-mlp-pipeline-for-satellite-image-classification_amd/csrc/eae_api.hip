@@ -45,7 +45,7 @@ void param_sizes(const eae_config& c, long long* sz) {
 int check_cfg(const eae_config* c) {
   if (!c) return eae_set_error(EAE_ERR_ARG, "config is NULL");
   if (c->image_h <= 0 || c->image_w <= 0 || c->image_h % 64 || c->image_w % 64) return eae_set_error(EAE_ERR_ARG, "image size must be a positive multiple of 64");
-  if (c->latent_dim <= 0 || c->latent_dim % 64) return eae_set_error(EAE_ERR_ARG, "latent_dim must be a positive multiple of 64");
+  if (c->latent_dim <= 0 || c->latent_dim > 256) return eae_set_error(EAE_ERR_ARG, "latent_dim must be in 1..256");
   if (c->num_classes <= 0 || c->num_classes > 16) return eae_set_error(EAE_ERR_ARG, "num_classes must be in 1..16");
   if (c->max_batch <= 0) return eae_set_error(EAE_ERR_ARG, "max_batch must be positive");
   return 0;
@@ -56,6 +56,13 @@ int check_cfg(const eae_config* c) {
 struct eae_ctx {
   eae_config cfg;
   int H, W, L, C, Bm;
+  // The latent-projection kernels work on a latent width padded to a multiple of 64 (Lp): the padded weight rows / columns are
+  // zero in the packs, so the padded latent columns are exactly zero.  When Lp != L (`lpad`) the kernels that produce gradients in
+  // parameter layout write padded shadows (gs_*), which compact_* copies into the gradient arena; with Lp == L they write the arena.
+  int Lp = 0;
+  bool lpad = false;
+  float *gs_encw = nullptr, *gs_encb = nullptr, *gs_decw = nullptr, *gs_head = nullptr, *zstage = nullptr;
+  size_t pk_w1p = 0, pk_bep = 0;     // lpad: fp32 copies of classifier.0.weight [128][Lp] and enc.fc.bias [Lp]
   long long Pn, K;                 // pixels of the 256-channel map, flattened features
   long long poff[39], bnoff[15];
   float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *bnrun = nullptr;
@@ -176,6 +183,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   if (int rc = check_cfg(cfg)) return rc;
   eae_ctx* c = new eae_ctx();
   c->cfg = *cfg; c->H = cfg->image_h; c->W = cfg->image_w; c->L = cfg->latent_dim; c->C = cfg->num_classes; c->Bm = cfg->max_batch;
+  c->Lp = (c->L + 63) / 64 * 64; c->lpad = c->Lp != c->L;
   c->Pn = (long long)(c->H / 16) * (c->W / 16); c->K = 256 * c->Pn;
   eae_ae_layout(cfg, c->poff, c->bnoff);
   const long long Bm = c->Bm;
@@ -186,7 +194,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   for (int i = 0; i < 4; ++i) { o_y[i] = carve(Bm * c->act_elems(i + 1) * 2); o_gy[i] = carve(Bm * c->act_elems(i + 1) * 2); }
   for (int i = 0; i < 3; ++i) { o_u[i] = carve(Bm * c->act_elems(3 - i) * 2); o_gu[i] = carve(Bm * c->act_elems(3 - i) * 2); }
   size_t o_d0 = carve(Bm * c->K * 2), o_gd0 = carve(Bm * c->K * 2), o_g4 = carve(Bm * (size_t)c->H * c->W * 4 * 2);
-  size_t o_z = carve(Bm * c->L * 4), o_dz = carve(Bm * c->L * 4), o_dzc = carve(Bm * c->L * 4);
+  size_t o_z = carve(Bm * c->Lp * 4), o_dz = carve(Bm * c->Lp * 4), o_dzc = carve(Bm * c->Lp * 4);
   size_t o_cf[7], o_cb[7];
   for (int l = 0; l < 7; ++l) { o_cf[l] = carve(4 * BN_C[l] * 4); o_cb[l] = carve(3 * BN_C[l] * 4); }
   // statistics partials: the largest producer is conv1 / deconv4-backward (tiles x 2 x 32) or enc.fc backward (mtiles*P x 2 x 256)
@@ -228,10 +236,15 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   }
   size_t o_accb = carve(2 * acc_total);  // forward accumulators, then the backward ones (cleared together)   // conv1 weight gradient (last kernel of the backward, runs on the main stream)
   const int ksplit = (int)(c->K / 128);
-  size_t o_fcp = carve((size_t)ksplit * Bm * c->L * 4);
+  size_t o_fcp = carve((size_t)ksplit * Bm * c->Lp * 4);
   size_t o_mse = carve(std::max((size_t)eae_edge_tiles((int)Bm, c->H, c->W), (size_t)((Bm * c->H * c->W + 255) / 256)) * 4 * 4);
   const long long hb = eae_head_blocks((int)Bm);
-  c->head_stride = r4(128LL * c->L) + 128 + r4(128LL * c->C) + r4(c->C);
+  c->head_stride = r4(128LL * c->Lp) + 128 + r4(128LL * c->C) + r4(c->C);
+  size_t o_gsew = 0, o_gseb = 0, o_gsdw = 0, o_gsh = 0, o_zst = 0;
+  if (c->lpad) {
+    o_gsew = carve((size_t)c->Lp * c->K * 4); o_gseb = carve((size_t)c->Lp * 4); o_gsdw = carve((size_t)c->K * c->Lp * 4);
+    o_gsh = carve((size_t)c->head_stride * 4); o_zst = carve(Bm * c->Lp * 4);
+  }
   size_t o_ce = carve(hb * 2 * 4), o_head = carve(hb * c->head_stride * 4), o_loss = carve(64 * 4), o_dyn = carve(64), o_sig = carve(64);
   // ---- pack arena
   size_t poffb = 0;
@@ -239,6 +252,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   std::vector<PackDesc> descs;
   auto add = [&](long long src, size_t dst, long long cnt, int mode, int d0, int d1, int d2, int f32) {
     PackDesc d; d.src_off = src; d.dst_off = (long long)dst; d.count = cnt; d.mode = mode; d.d0 = d0; d.d1 = d1; d.d2 = d2; d.out_f32 = f32;
+    d.lv = d0;
     descs.push_back(d);
   };
   c->pk_c1 = pcarve(32 * 64 * 2); add(c->poff[0], c->pk_c1, 32 * 64, PACK_K36, 32, 3, 0, 0);
@@ -249,11 +263,16 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   }
   c->pk_d4j = pcarve(16 * 128 * 2); add(c->poff[32], c->pk_d4j, 16 * 128, PACK_DECONV4_JOINT, 0, 0, 0, 0);
   c->pk_d4k = pcarve(32 * 64 * 2); add(c->poff[32], c->pk_d4k, 32 * 64, PACK_K36, 32, 3, 0, 0);
-  const long long LK = c->L * c->K;
-  c->pk_we1 = pcarve(LK * 2); add(c->poff[16], c->pk_we1, LK, PACK_FC_ROWMAJOR_KPERM, c->L, 256, (int)c->Pn, 0);
-  c->pk_we2 = pcarve(LK * 2); add(c->poff[16], c->pk_we2, LK, PACK_FC_TRANS_KPERM, c->L, 256, (int)c->Pn, 0);
-  c->pk_wd1 = pcarve(LK * 2); add(c->poff[18], c->pk_wd1, LK, PACK_FC_ROWPERM, c->L, 256, (int)c->Pn, 0);
-  c->pk_wd2 = pcarve(LK * 2); add(c->poff[18], c->pk_wd2, LK, PACK_FC_ROWPERM_TRANS, c->L, 256, (int)c->Pn, 0);
+  const long long LK = c->Lp * c->K;      // d0 = padded latent width, lv = the real one (rows / columns beyond it are zero)
+  c->pk_we1 = pcarve(LK * 2); add(c->poff[16], c->pk_we1, LK, PACK_FC_ROWMAJOR_KPERM, c->Lp, 256, (int)c->Pn, 0);
+  c->pk_we2 = pcarve(LK * 2); add(c->poff[16], c->pk_we2, LK, PACK_FC_TRANS_KPERM, c->Lp, 256, (int)c->Pn, 0);
+  c->pk_wd1 = pcarve(LK * 2); add(c->poff[18], c->pk_wd1, LK, PACK_FC_ROWPERM, c->Lp, 256, (int)c->Pn, 0);
+  c->pk_wd2 = pcarve(LK * 2); add(c->poff[18], c->pk_wd2, LK, PACK_FC_ROWPERM_TRANS, c->Lp, 256, (int)c->Pn, 0);
+  for (int k = 0; k < 4; ++k) descs[descs.size() - 1 - k].lv = c->L;
+  if (c->lpad) {
+    c->pk_w1p = pcarve(128LL * c->Lp * 4); add(c->poff[34], c->pk_w1p, 128LL * c->Lp, PACK_PAD_COLS, c->Lp, 0, 0, 1); descs.back().lv = c->L;
+    c->pk_bep = pcarve(c->Lp * 4); add(c->poff[17], c->pk_bep, c->Lp, PACK_PAD_COLS, c->Lp, 0, 0, 1); descs.back().lv = c->L;
+  }
   c->pk_bd = pcarve(c->K * 4); add(c->poff[19], c->pk_bd, c->K, PACK_FC_ROWPERM, 1, 256, (int)c->Pn, 1);
   c->ndesc = (int)descs.size();
   size_t o_pack = carve(poffb), o_desc = carve(descs.size() * sizeof(PackDesc));
@@ -264,6 +283,10 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   for (int i = 0; i < 3; ++i) { c->u[i] = (bf16_t*)(b + o_u[i]); c->gu[i] = (bf16_t*)(b + o_gu[i]); }
   c->d0 = (bf16_t*)(b + o_d0); c->gd0 = (bf16_t*)(b + o_gd0); c->g4 = (bf16_t*)(b + o_g4);
   c->z = (float*)(b + o_z); c->dz = (float*)(b + o_dz); c->dzc = (float*)(b + o_dzc);
+  if (c->lpad) {
+    c->gs_encw = (float*)(b + o_gsew); c->gs_encb = (float*)(b + o_gseb); c->gs_decw = (float*)(b + o_gsdw);
+    c->gs_head = (float*)(b + o_gsh); c->zstage = (float*)(b + o_zst);
+  }
   for (int l = 0; l < 7; ++l) { c->coef_f[l] = (float*)(b + o_cf[l]); c->coef_b[l] = (float*)(b + o_cb[l]); }
   c->stat = (float*)(b + o_stat); c->wscratch = (float*)(b + o_wscr); c->wscratch_main = (float*)(b + o_wscrm);
   c->acc_base = b + o_accb; c->acc_bytes = (2 * acc_total + 15) & ~(size_t)15;
@@ -280,6 +303,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->use_graph = getenv("EAE_GRAPH") != nullptr && getenv("EAE_NO_GRAPH") == nullptr;
   e = hipMemcpy(c->descs_dev, descs.data(), descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(c->g4, 0, Bm * (size_t)c->H * c->W * 4 * 2);
+  if (e == hipSuccess && c->lpad) e = hipMemset(c->zstage, 0, Bm * (size_t)c->Lp * 4);
   if (e == hipSuccess) e = hipMemset(c->acc_base, 0, c->acc_bytes);
   if (e == hipSuccess) e = hipMemset(c->sigwords, 0, 64);
   c->acc_clean = true;
@@ -651,6 +675,20 @@ int bn_bwd_fin(eae_ctx* c, hipStream_t st, int l, int ntiles, long long count) {
                                     c->G + c->poff[BN_GAMMA_IDX[l]], c->G + c->poff[BN_GAMMA_IDX[l] + 1], c->coef_b[l]);
 }
 
+// latent-width padding (eae_ctx::Lp): copies between the caller's [B][L] tensors and the padded [B][Lp] workspace rows
+int copy_latent_out(eae_ctx* c, hipStream_t st, float* dst, const float* src_padded, int B) {
+  if (!c->lpad) { EAE_HIP(hipMemcpyAsync(dst, src_padded, (size_t)B * c->L * 4, hipMemcpyDeviceToDevice, st)); return 0; }
+  EAE_HIP(hipMemcpy2DAsync(dst, (size_t)c->L * 4, src_padded, (size_t)c->Lp * 4, (size_t)c->L * 4, B, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+const float* stage_latent_in(eae_ctx* c, hipStream_t st, const float* src, int B, int* rc) {
+  *rc = 0;
+  if (!c->lpad || !src) return src;
+  hipError_t e = hipMemcpy2DAsync(c->zstage, (size_t)c->Lp * 4, src, (size_t)c->L * 4, (size_t)c->L * 4, B, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) { *rc = eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); return nullptr; }
+  return c->zstage;          // padding columns stay zero (cleared once at creation, never written)
+}
+
 // ---- encoder: x -> y[0..3] (raw, bf16) + BN coefficients -> z (fp32)
 int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
   const int H = c->H, W = c->W;
@@ -683,11 +721,12 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
   FcNtArgs f = FcNtArgs();
   f.a = src_bnrelu(c->y[3], c->coef_f[3]);
   f.w = (const bf16_t*)(c->pack + c->pk_we1);
-  f.M = B; f.N = c->L; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
+  f.M = B; f.N = c->Lp; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
   fold_consumer(c, f.fold, 3, (long long)B * c->Pn, train);
   const int ksplit = (int)(c->K / 128);
   RC(eae_launch_fc_nt(st, f, SRC_BNRELU, FCE_PARTIAL, ksplit));
-  RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, c->P + c->poff[17], nullptr, nullptr, c->z));
+  RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->Lp, c->lpad ? (const float*)(c->pack + c->pk_bep) : c->P + c->poff[17], nullptr,
+                          nullptr, c->z));
   return 0;
 }
 
@@ -701,7 +740,7 @@ int run_decoder(eae_ctx* c, hipStream_t st, const float* z, int B, bool train, c
     FcNtArgs f = FcNtArgs();
     f.a = src_f32(z);
     f.w = (const bf16_t*)(c->pack + c->pk_wd1);
-    f.M = B; f.N = (int)c->K; f.K = c->L; f.klen = c->L;
+    f.M = B; f.N = (int)c->K; f.K = c->Lp; f.klen = c->Lp;
     f.c = ConvArgs();
     f.c.out = c->d0; f.c.bias = (const float*)(c->pack + c->pk_bd);
     take_sig(c, f.c);
@@ -740,8 +779,8 @@ int run_decoder(eae_ctx* c, hipStream_t st, const float* z, int B, bool train, c
 int run_head(eae_ctx* c, hipStream_t st, int B, const long long* labels, float* logits, bool want_grad, const float* dlogits_in) {
   HeadArgs h = HeadArgs();
   h.dlogits_in = dlogits_in;
-  h.z = c->z; h.w1 = c->P + c->poff[34]; h.b1 = c->P + c->poff[35]; h.w2 = c->P + c->poff[36]; h.b2 = c->P + c->poff[37];
-  h.labels = labels; h.B = B; h.L = c->L; h.C = c->C; h.inv_batch = 1.0f / (float)B;
+  h.z = c->z; h.w1 = c->lpad ? (const float*)(c->pack + c->pk_w1p) : c->P + c->poff[34]; h.b1 = c->P + c->poff[35]; h.w2 = c->P + c->poff[36]; h.b2 = c->P + c->poff[37];
+  h.labels = labels; h.B = B; h.L = c->Lp; h.C = c->C; h.inv_batch = 1.0f / (float)B;
   h.logits = logits; h.dz = c->dzc; h.grad_part = want_grad ? c->headpart : nullptr; h.grad_stride = c->head_stride;
   h.loss_part = c->cepart;
   return eae_launch_head(st, h);
@@ -789,7 +828,7 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
     }
   }
   RC(run_decoder(c, st, c->z, B, train, (want_loss || want_grad) ? io->x : nullptr, gscale, io->x_hat, want_grad, want_loss));
-  if (io->z) EAE_HIP(hipMemcpyAsync(io->z, c->z, (size_t)B * c->L * 4, hipMemcpyDeviceToDevice, st));
+  if (io->z) RC(copy_latent_out(c, st, io->z, c->z, B));
   if (want_loss || want_grad) {
     const int n_ce = (head && io->labels) ? eae_head_blocks(B) : 0;
     // in a gradient step nothing on the main stream reads what this kernel writes (deconv4 bias gradient, loss scalars):
@@ -829,8 +868,14 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
       sq_push(c, [=](hipStream_t ss, float*) {
         const int nb = eae_head_blocks(B);
         hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(c->head_stride / 4)), dim3(256), 0, ss, c->headpart, nb,
-                           (long)(c->head_stride / 4), c->G + c->poff[34], 1.0f);
+                           (long)(c->head_stride / 4), c->lpad ? c->gs_head : c->G + c->poff[34], 1.0f);
         EAE_LAUNCH_CHECK();
+        if (c->lpad) {     // padded shadow -> arena: classifier.0.weight [128][L], then bias / classifier.2 (contiguous)
+          EAE_HIP(hipMemcpy2DAsync(c->G + c->poff[34], (size_t)c->L * 4, c->gs_head, (size_t)c->Lp * 4, (size_t)c->L * 4, 128,
+                                   hipMemcpyDeviceToDevice, ss));
+          EAE_HIP(hipMemcpyAsync(c->G + c->poff[35], c->gs_head + 128LL * c->Lp, (size_t)(c->poff[38] - c->poff[35]) * 4,
+                                 hipMemcpyDeviceToDevice, ss));
+        }
         return 0;
       }, 0);
     } else {
@@ -899,22 +944,28 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     // ---- dec.fc: weight/bias gradient (queued: needs gd0) and dz
     sq_push(c, [=](hipStream_t s2, float*) {
       FcTnArgs t = FcTnArgs();
-      t.p = src_raw(c->gd0); t.q = src_f32(c->z); t.Bt = B; t.I = (int)c->K; t.J = c->L;
-      t.out = c->G + c->poff[18]; t.colsum = c->G + c->poff[19]; t.out_mode = 0; t.Pn = (int)c->Pn;
-      return eae_launch_fc_tn(s2, t, SRC_RAW, SRC_F32);
+      t.p = src_raw(c->gd0); t.q = src_f32(c->z); t.Bt = B; t.I = (int)c->K; t.J = c->Lp;
+      t.out = c->lpad ? c->gs_decw : c->G + c->poff[18]; t.colsum = c->G + c->poff[19]; t.out_mode = 0; t.Pn = (int)c->Pn;
+      RC(eae_launch_fc_tn(s2, t, SRC_RAW, SRC_F32));
+      if (c->lpad) EAE_HIP(hipMemcpy2DAsync(c->G + c->poff[18], (size_t)c->L * 4, c->gs_decw, (size_t)c->Lp * 4, (size_t)c->L * 4,
+                                            (size_t)c->K, hipMemcpyDeviceToDevice, s2));
+      return 0;
     });
     fork_if_every();
     {
       FcNtArgs f = FcNtArgs();
       f.a = src_raw(c->gd0); f.w = (const bf16_t*)(c->pack + c->pk_wd2);
-      f.M = B; f.N = c->L; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
+      f.M = B; f.N = c->Lp; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
       f.c = ConvArgs();
       take_sig(c, f.c);
       const int ksplit = (int)(c->K / 128);
       RC(eae_launch_fc_nt(st, f, SRC_RAW, FCE_PARTIAL, ksplit));
       if (c->sq_forked) RC(sq_commit(c, st));
       if (c->head_pending) { EAE_HIP(hipStreamWaitEvent(st, c->ev_head, 0)); c->head_pending = false; }
-      RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->L, nullptr, head ? c->dzc : nullptr, dz_ext, c->dz));
+      int src_rc = 0;
+      const float* dze = stage_latent_in(c, st, dz_ext, B, &src_rc);      // caller's [B][L] gradient -> padded rows
+      RC(src_rc);
+      RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->Lp, nullptr, head ? c->dzc : nullptr, dze, c->dz));
     }
     if (dp) RC(sq_commit(c, st));  // the hand-off below covers gradient tensors 18..37 only (ordered after `st` as it stands)
   }   // part != 2
@@ -927,15 +978,20 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
   // ---- enc.fc: weight/bias gradient (queued with the dec.fc one: needs dz) and backward-data into y[3]'s BN+ReLU
   sq_push(c, [=](hipStream_t s2, float*) {
     FcTnArgs t = FcTnArgs();
-    t.p = src_f32(c->dz); t.q = src_bnrelu(c->y[3], c->coef_f[3]); t.Bt = B; t.I = c->L; t.J = (int)c->K;
-    t.out = c->G + c->poff[16]; t.colsum = c->G + c->poff[17]; t.out_mode = 1; t.Pn = (int)c->Pn;
-    return eae_launch_fc_tn(s2, t, SRC_F32, SRC_BNRELU);
+    t.p = src_f32(c->dz); t.q = src_bnrelu(c->y[3], c->coef_f[3]); t.Bt = B; t.I = c->Lp; t.J = (int)c->K;
+    t.out = c->lpad ? c->gs_encw : c->G + c->poff[16]; t.colsum = c->lpad ? c->gs_encb : c->G + c->poff[17]; t.out_mode = 1; t.Pn = (int)c->Pn;
+    RC(eae_launch_fc_tn(s2, t, SRC_F32, SRC_BNRELU));
+    if (c->lpad) {       // the first L rows of the padded shadows are the arena tensors
+      EAE_HIP(hipMemcpyAsync(c->G + c->poff[16], c->gs_encw, (size_t)c->L * c->K * 4, hipMemcpyDeviceToDevice, s2));
+      EAE_HIP(hipMemcpyAsync(c->G + c->poff[17], c->gs_encb, (size_t)c->L * 4, hipMemcpyDeviceToDevice, s2));
+    }
+    return 0;
   });
   sq_fork(c);
   {
     FcNtArgs f = FcNtArgs();
     f.a = src_f32(c->dz); f.w = (const bf16_t*)(c->pack + c->pk_we2);
-    f.M = B; f.N = (int)c->K; f.K = c->L; f.klen = c->L;
+    f.M = B; f.N = (int)c->K; f.K = c->Lp; f.klen = c->Lp;
     f.c = ConvArgs();
     f.c.out = c->gy[3]; f.c.stat_part = c->stat; f.c.yprev = c->y[3]; f.c.prev_coef = c->coef_f[3];
     fold_bwd_producer(c, f.c, 3);
@@ -1146,8 +1202,7 @@ extern "C" int eae_encoder_forward(eae_ctx* c, void* stream, const float* x, int
   RC(ensure_packed(c, st));
   RC(prep_accumulators(c, st, train != 0));
   RC(run_encoder(c, st, x, B, train != 0));
-  EAE_HIP(hipMemcpyAsync(z, c->z, (size_t)B * c->L * 4, hipMemcpyDeviceToDevice, st));
-  return 0;
+  return copy_latent_out(c, st, z, c->z, B);
 }
 
 extern "C" int eae_decoder_forward(eae_ctx* c, void* stream, const float* z, int B, int train, float* x_hat) {
@@ -1158,7 +1213,10 @@ extern "C" int eae_decoder_forward(eae_ctx* c, void* stream, const float* z, int
   c->fwd_ready = false;
   RC(ensure_packed(c, st));
   RC(prep_accumulators(c, st, train != 0));
-  return run_decoder(c, st, z, B, train != 0, nullptr, 0.f, x_hat, false, false);
+  int src_rc = 0;
+  const float* zp = stage_latent_in(c, st, z, B, &src_rc);
+  RC(src_rc);
+  return run_decoder(c, st, zp, B, train != 0, nullptr, 0.f, x_hat, false, false);
 }
 
 // ------------------------------------------------------------------------------------------- per-op wrappers

@@ -3,7 +3,7 @@
 #include <stdint.h>
 
 enum { PACK_COPY = 0, PACK_3x3_P1, PACK_3x3_P2, PACK_K27, PACK_DECONV4_JOINT, PACK_FC_ROWMAJOR_KPERM, PACK_FC_TRANS_KPERM,
-       PACK_FC_ROWPERM, PACK_FC_ROWPERM_TRANS, PACK_K36 };
+       PACK_FC_ROWPERM, PACK_FC_ROWPERM_TRANS, PACK_K36, PACK_PAD_COLS };
 
 struct PackDesc {
   long long src_off;   // element offset into the fp32 parameter arena
@@ -11,6 +11,7 @@ struct PackDesc {
   long long count;     // destination elements
   int mode, d0, d1, d2;
   int out_f32;         // 1: destination is fp32 (permuted biases), 0: bf16
+  int lv;              // FC modes / PACK_PAD_COLS: number of REAL entries along the latent dimension d0 (the rest of d0 is zero padding)
 };
 
 int eae_launch_bn_finalize(hipStream_t st, const float* part, int ntiles, int C, long long count, const float* gamma,

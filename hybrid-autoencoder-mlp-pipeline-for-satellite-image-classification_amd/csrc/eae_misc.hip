@@ -228,25 +228,35 @@ __device__ __forceinline__ float pack_fetch(const PackDesc& d, const float* __re
       if (ky < 0 || kx < 0) return 0.f;
       return src[(ci * 3 + co) * 9 + ky * 3 + kx];
     }
+    // FC modes: d0 = latent width PADDED to a multiple of 64, d.lv = the real width (rows / columns >= lv are zero; the source
+    // tensor has lv of them)
     case PACK_FC_ROWMAJOR_KPERM: {   // dst [R][K'] with k' = p*Cc + c  <- src [R][K] with k = c*P + p   (d0=R, d1=Cc, d2=P)
       unsigned K = d1 * d2, k2 = i % K, r = i / K;
+      if (r >= (unsigned)d.lv) return 0.f;
       unsigned c = k2 % d1, p = k2 / d1;
       return src[r * K + c * d2 + p];
     }
     case PACK_FC_TRANS_KPERM: {      // dst [K'][R]  <- src [R][K]   (transpose + permute)
       unsigned r = i % d0, k2 = i / d0, K = d1 * d2;
+      if (r >= (unsigned)d.lv) return 0.f;
       unsigned c = k2 % d1, p = k2 / d1;
       return src[r * K + c * d2 + p];
     }
     case PACK_FC_ROWPERM: {          // dst [J'][L] with j' = p*Cc + c <- src [J][L] with j = c*P + p   (d0=L, d1=Cc, d2=P)
       unsigned l = i % d0, j2 = i / d0;
+      if (l >= (unsigned)d.lv) return 0.f;
       unsigned c = j2 % d1, p = j2 / d1;
-      return src[(c * d2 + p) * d0 + l];
+      return src[(c * d2 + p) * (unsigned)d.lv + l];
     }
     case PACK_FC_ROWPERM_TRANS: {    // dst [L][J']  <- src [J][L]
       unsigned J = d1 * d2, j2 = i % J, l = i / J;
+      if (l >= (unsigned)d.lv) return 0.f;
       unsigned c = j2 % d1, p = j2 / d1;
-      return src[(c * d2 + p) * d0 + l];
+      return src[(c * d2 + p) * (unsigned)d.lv + l];
+    }
+    case PACK_PAD_COLS: {            // dst [R][d0] <- src [R][lv], zero beyond column lv
+      unsigned l = i % d0, r = i / d0;
+      return l < (unsigned)d.lv ? src[r * (unsigned)d.lv + l] : 0.f;
     }
     default: return src[i];          // PACK_COPY
   }

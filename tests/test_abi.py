@@ -56,9 +56,10 @@ def test_layout_matches_module_shells(lib):
 
 
 def test_error_convention(lib):
-    bad = _lib.EaeConfig(63, 10, 64, 64, 8)
-    rc = lib.eae_ae_layout(C.byref(bad), None, None)
-    assert rc == -2 and b"latent_dim" in lib.eae_last_error()
+    for latent in (0, 257):          # any width in 1..256 is accepted (padded to a multiple of 64 inside the engine)
+        bad = _lib.EaeConfig(latent, 10, 64, 64, 8)
+        rc = lib.eae_ae_layout(C.byref(bad), None, None)
+        assert rc == -2 and b"latent_dim" in lib.eae_last_error()
     bad = _lib.EaeConfig(64, 10, 60, 64, 8)
     assert lib.eae_ae_layout(C.byref(bad), None, None) == -2
     with pytest.raises(_lib.EaeError):

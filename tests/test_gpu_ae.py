@@ -187,6 +187,65 @@ def test_eval_b1_and_latent128(golden):
     assert np.abs(z.cpu().numpy() - g["z"]).max() <= 0.02 * np.abs(g["z"]).max()
 
 
+@pytest.mark.parametrize("latent", [48])
+def test_latent_width_not_a_multiple_of_64_vs_golden(golden, latent):
+    """The reference takes any latent_dim (R.md:309, 365, 423); the engine pads the latent width to a multiple of 64 inside its
+    packs and workspaces.  ae_latent48_b8.npz (reference run): forward, loss, gradient digests of every parameter, parameters
+    after one Adam step; plus the encoder -> decoder entry points and the autograd path with caller-side [B][48] latents."""
+    import gpu_util as G
+    g = golden(f"ae_latent{latent}_b8.npz")
+    x, y = gu.make_images(8, int(g["seed"]))
+    m = _model(latent)
+    eng = _engine(m)
+    xh, lg, z = eng.forward(_cuda(x), labels=_cuda(y), train=True, alpha=float(g["alpha"]))
+    torch.cuda.synchronize()
+    assert tuple(z.shape) == (8, latent)
+    d = np.abs(xh.cpu().numpy().ravel()[::7] - g["x_hat"])
+    assert d.max() <= 3e-2 and d.mean() <= 3e-3
+    assert np.abs(z.cpu().numpy() - g["z"]).max() <= 0.02 * np.abs(g["z"]).max()
+    assert np.abs(lg.cpu().numpy() - g["logits"]).max() <= 0.02 * np.abs(g["logits"]).max()
+    assert abs(eng.loss_last.cpu().numpy()[0] - g["loss"]) <= 0.02 * abs(g["loss"])
+    # encoder / decoder entry points with the caller's unpadded latent
+    z2 = eng.encoder(_cuda(x), train=False)
+    xh2 = eng.decoder(z2, train=False)
+    xh3, _, z3 = eng.forward(_cuda(x), train=False)
+    torch.cuda.synchronize()
+    assert torch.equal(z2, z3) and torch.equal(xh2, xh3)
+    # gradients
+    eng.grad_step(_cuda(x), _cuda(y), float(g["alpha"]))
+    torch.cuda.synchronize()
+    eng.expose_grads()
+    bad = []
+    for name, prm in m.named_parameters():
+        got = prm.grad.cpu().numpy()
+        dg, smp = g[f"grad/{name}/digest"], g[f"grad/{name}/sample"]
+        if dg[1] < 1e-6:
+            assert np.abs(got).max() == 0.0, name
+            continue
+        dd, s = gu.tensor_digest(got)
+        ratio = dd[1] / dg[1]
+        cos = G.cosine(s, smp) if smp.size >= 100 else 1.0
+        if not (0.95 <= ratio <= 1.05 and cos > 0.975):
+            bad.append((name, round(ratio, 4), round(cos, 4)))
+    assert not bad, bad
+    # one Adam step: -lr * sign(g) elementwise (as test_one_adam_step_elementwise_vs_golden)
+    m = _model(latent)
+    eng = _engine(m)
+    lr = float(g["lr"])
+    eng.train_step(_cuda(x), _cuda(y), float(g["alpha"]), lr)
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    for k in g.files:
+        if not (k.startswith("final/") and k.endswith("/sample")):
+            continue
+        name = k[6:-7]
+        if "running" in name or "num_batches" in name or gu.is_prebn_bias(name):
+            continue
+        _, s = gu.tensor_digest(sd[name])
+        err = np.abs(s - g[k])
+        assert err.max() <= 2 * lr + 1e-4 and (s.size < 50 or float(np.mean(err < 1e-4)) >= 0.90), (name, float(err.max()))
+
+
 @pytest.mark.parametrize("tag,head", [("joint", True), ("recon", False)])
 def test_adam_trajectory_vs_golden(golden, tag, head):
     g = golden(f"ae_adam5_{tag}_b8.npz")

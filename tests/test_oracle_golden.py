@@ -121,6 +121,23 @@ def test_ae_eval_b1_and_latent128(golden):
     assert abs(l_c - g["ce"]) < 1e-5 and abs(l_r - g["mse"]) < 1e-6
 
 
+def test_ae_latent48(golden):
+    """A latent width that is not a multiple of 64 (ae_latent48_b8.npz, reference run): forward, loss and every gradient."""
+    g = golden("ae_latent48_b8.npz")
+    p = ae_state_np(48)
+    x, y = gu.make_images(8, int(g["seed"]))
+    out = O.ae_forward(p, x, train=True)
+    np.testing.assert_allclose(out["x_hat"].ravel()[::7], g["x_hat"], atol=1e-5)
+    assert np.abs(out["z"] - g["z"]).max() < 5e-5 and np.abs(out["logits"] - g["logits"]).max() < 5e-5
+    loss, _, _ = O.ae_loss(out, x, y, float(g["alpha"]))
+    assert abs(loss - g["loss"]) < 2e-5 * max(1, abs(g["loss"]))
+    gr = O.ae_backward(p, out, x, y, float(g["alpha"]))
+    for k in g.files:
+        if k.startswith("grad/") and k.endswith("/digest") and g[k][1] >= 1e-5:
+            name = k[5:-7]
+            digest_close(gr[name], g[k], g[f"grad/{name}/sample"], rtol=3e-3)
+
+
 @pytest.mark.parametrize("tag,head", [("joint", True), ("recon", False)])
 def test_ae_adam_trajectory(golden, tag, head):
     g = golden(f"ae_adam5_{tag}_b8.npz")

@@ -126,12 +126,41 @@ def gen_round2(ref):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1e6:.2f} MB")
 
 
+def gen_latent48(ref):
+    """`python tools/make_golden.py --latent48`: ae_latent48_b8.npz -- a latent width that is NOT a multiple of 64 (the reference
+    takes any integer, R.md:309, 365, 423): train-mode forward, loss, gradient digests of every parameter, and the parameters
+    after one Adam step, at B=8."""
+    SAE = ref["SupervisedAutoencoder"]
+    torch.manual_seed(gu.AE_SEED)
+    m = SAE(latent_dim=48, num_classes=10)
+    load_np(m, gu.perturb_bn(sd_np(m)))
+    m.train()
+    alpha, lr = 35.0, 5e-3
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    x, y = gu.make_images(8, 100)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    opt.zero_grad()
+    xh, lg, z = m(xt)
+    loss = alpha * nn.MSELoss()(xh, xt) + nn.CrossEntropyLoss()(lg, yt)
+    loss.backward()
+    st = {"alpha": np.float32(alpha), "lr": np.float32(lr), "seed": np.int64(100), "loss": np.float32(loss.item()),
+          "x_hat": xh.detach().numpy().ravel()[::7].copy(), "logits": lg.detach().numpy(), "z": z.detach().numpy()}
+    digest_sd({k: p.grad.detach().numpy() for k, p in m.named_parameters()}, "grad", st)
+    opt.step()
+    digest_sd(sd_np(m), "final", st)
+    np.savez_compressed(os.path.join(OUT, "ae_latent48_b8.npz"), **st)
+    print(f"  ae_latent48_b8.npz: {os.path.getsize(os.path.join(OUT, 'ae_latent48_b8.npz')) / 1e6:.2f} MB")
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
     if "--round2" in sys.argv:
         gen_round2(ref)
+        return
+    if "--latent48" in sys.argv:
+        gen_latent48(ref)
         return
     SAE, MLP, Encoder, Decoder = ref["SupervisedAutoencoder"], ref["MLP"], ref["Encoder"], ref["Decoder"]
 
