@@ -217,7 +217,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
     if (getenv("EAE_ONE_SIDE_STREAM")) c->nx = 0;
   }
   for (int i = 0; i < c->nx; ++i) o_wscrx[i] = carve(c->wscratch_floats * 4);
-  size_t o_wscrm = carve((size_t)512 * 864 * 4);
+  size_t o_wscrm = carve((size_t)2048 * 864 * 4);
   size_t o_acc[7], acc_total = 0;
   {
     const int Bi = (int)Bm;
@@ -1040,7 +1040,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
   BnBwdFold bf0;
   fold_bwd_consumer(c, bf0, 0, (long long)B * (H / 2) * (W / 2), true);
   RC(eae_launch_edge_wgrad(st, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, c->wscratch_main,
-                           512LL * 864, c->G + c->poff[0], prof_hook_for(c, EAE_PROF_CONV1_WGRAD), &bf0));
+                           2048LL * 864, c->G + c->poff[0], prof_hook_for(c, EAE_PROF_CONV1_WGRAD), &bf0));
   RC(join_side(c, st));
   // Biases in front of a BatchNorm have an identically zero gradient (the reference computes ~1e-9 rounding noise);
   // their slots in the gradient arena are zeroed once in eae_bind and never written.

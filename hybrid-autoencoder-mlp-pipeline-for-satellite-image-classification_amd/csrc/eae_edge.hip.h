@@ -179,9 +179,13 @@ struct EdgeWgradArgs {
 template <int SRC3, int SMODE>
 __global__ __launch_bounds__(256) void edge_wgrad_kernel(EdgeWgradArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t p3[E_PATCH];
-  __shared__ __attribute__((aligned(16))) bf16_t at[E_AT];
-  __shared__ __attribute__((aligned(16))) bf16_t st[E_AT];
-  __shared__ __attribute__((aligned(16))) float racc[4][2][2][64 * 4];
+  // the two operand tiles; the cross-wave reduction image of the epilogue (16 KB) reuses them (41.9 -> 26 KB of LDS per block:
+  // 6 instead of 3 blocks per CU)
+  static_assert(2 * E_AT * sizeof(bf16_t) >= 4 * 2 * 2 * 64 * 4 * sizeof(float), "reduction image must fit the operand tiles");
+  __shared__ __attribute__((aligned(16))) bf16_t tiles[2 * E_AT];
+  bf16_t* const at = tiles;
+  bf16_t* const st = tiles + E_AT;
+  float (*racc)[2][2][64 * 4] = reinterpret_cast<float (*)[2][2][64 * 4]>(tiles);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Hout = a.H >> 1, Wout = a.W >> 1;
   const int tiles_x = Wout / E_TW, tiles_y = Hout / E_TH;
@@ -242,6 +246,7 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(EdgeWgradArgs a) {
       for (int jt = 0; jt < 2; ++jt) acc[it][jt] = mfma16(ka[it], sb[jt], acc[it][jt]);
   }
   // cross-wave reduction (fixed order) and store in reference layout
+  __syncthreads();            // every wave has read its fragments of the last tile: the image may overwrite the tiles
 #pragma unroll
   for (int it = 0; it < 2; ++it)
 #pragma unroll

@@ -1,5 +1,6 @@
 // Host-side dispatch of the 3-channel edge-layer kernels (enc.conv1, dec.deconv4).
 #include "eae_internal.h"
+#include <cstdlib>
 #include "eae_edge.hip.h"
 #include "eae_wgrad.hip.h"
 
@@ -32,7 +33,9 @@ int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B
   a.bfold = bfold ? *bfold : BnBwdFold();
   a.src3 = src3; a.B = B; a.H = H; a.W = W; a.side = side; a.part = scratch;
   a.ntiles = eae_edge_tiles(B, H, W);
-  int nblocks = a.ntiles < 512 ? a.ntiles : 512;
+  static const int cap = getenv("EAE_EDGE_WGRAD_BLOCKS") ? atoi(getenv("EAE_EDGE_WGRAD_BLOCKS")) : 1024;   // 4 blocks per CU fit: one round of workgroups (0.510-0.514 vs 0.514-0.517 ms per step with 512)
+  int nblocks = a.ntiles < cap ? a.ntiles : cap;
+  while ((long long)nblocks * 864 > scratch_floats && nblocks > 1) nblocks /= 2;
   a.tiles_per_block = (a.ntiles + nblocks - 1) / nblocks;
   nblocks = (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
   if ((long long)nblocks * 864 > scratch_floats) return eae_set_error(-2, "edge_wgrad: scratch too small");

@@ -127,6 +127,41 @@ struct TileEpilogue {
       *reinterpret_cast<uint4*>(a.out + g) = v;
     }
   }
+  // EPI_MASK: the previous layer's raw tensor at this thread's rows of one pass, requested ahead of the pass (one exposed memory
+  // latency per pass instead of one per row group: the row loop below loads, waits, masks and stores one row group at a time --
+  // 8 serialised round trips in conv2's backward-data, 38 % of its workgroup lifetime by the stamps)
+  template <int NIT, class RowMap>
+  __device__ __forceinline__ void load_prev(const ConvArgs& a, int n0, int nrows, RowMap rowmap, uint4 (&yv)[NIT]) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = r0 + it * RPP;
+      const long off = row < nrows ? rowmap(row) : -1;
+      yv[it] = off >= 0 ? *reinterpret_cast<const uint4*>(a.yprev + (size_t)off + n0 + c * 8) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  template <int NIT, class RowMap>
+  __device__ __forceinline__ void rows_pre(const ConvArgs& a, const bf16_t* tile, int n0, int nrows, RowMap rowmap, const uint4 (&yv)[NIT]) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = r0 + it * RPP;
+      const long off = row < nrows ? rowmap(row) : -1;
+      if (off < 0) continue;
+      uint4 v = *reinterpret_cast<const uint4*>(tile + row * TS + c * 8);
+      const size_t g = (size_t)off + n0 + c * 8;
+      uint32_t w[4] = {v.x, v.y, v.z, v.w}, yw[4] = {yv[it].x, yv[it].y, yv[it].z, yv[it].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x2 y = up2(yw[j]);
+        f32x2 act = y * ps[j] + pt[j];
+        uint32_t m = (act.x > 0.f ? 0x0000ffffu : 0u) | (act.y > 0.f ? 0xffff0000u : 0u);
+        w[j] &= m;
+        f32x2 f = up2(w[j]);
+        s1[j] += f;
+        s2[j] += f * (y * pi[j] + pmi[j]);
+      }
+      *reinterpret_cast<uint4*>(a.out + g) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
   // deterministic reduction over the RPP row-groups that share a channel chunk; red = [2][RPP][BN] floats of LDS
   __device__ __forceinline__ void end(const ConvArgs& a, float* red, int n0, int tile_id) {
     if (EPI == EPI_PLAIN || (a.stat_part == nullptr && a.bacc.acc == nullptr) || (EPI == EPI_FWD && !VALU_STATS)) return;
@@ -314,15 +349,23 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
   BnFoldRegsB frb;
   const bool folded = SRC == SRC_BNRELU && a.fold.acc != nullptr;
   const bool folded_b = SRC == SRC_BNBWD && a.bfold.acc != nullptr;
+  // The 32-channel conv kind with two source tensors (dec.deconv3 backward-data) has 72 registers of raw pieces in flight at 4
+  // waves per SIMD: building the table underneath them spilled pieces to scratch (a reload waits for every load issued before it:
+  // 10-15 us per workgroup, measured with the stamps).  That instance builds its table BEFORE it requests the patch.
+  constexpr bool EARLY_TABLE = SRC == SRC_BNBWD && KIND == KIND_CONV && CIN == 32;
   if (folded) bn_fold_load<CIN>(a.fold, fr);
   if (folded_b) bn_fold_bwd_load<CIN>(a.bfold, frb);
+  if (EARLY_TABLE && folded_b) {
+    bn_fold_bwd_finish<CIN>(a.bfold, frb, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0);
+    coefp = coef_tab;
+  }
   if (SRC != SRC_BNBWD) load_w(0);
   issue(0, false);
   if (folded) {
     bn_fold_fwd_finish<CIN>(a.fold, fr, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0);
     coefp = coef_tab;
   }
-  if (folded_b) {
+  if (!EARLY_TABLE && folded_b) {
     bn_fold_bwd_finish<CIN>(a.bfold, frb, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0);
     coefp = coef_tab;
   }
@@ -419,6 +462,20 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
   float* red = reinterpret_cast<float*>(smem);     // aliases the tile: TileEpilogue::end() starts with a barrier after the last rows() pass
   TileEpilogue<COUT, BN, EPI, false> epi;
   epi.begin(a, n0);
+  auto rowmap_of = [=](int pass) {
+    return [=](int row2) -> long {
+      const int row = row2 / PHG, px = row2 % PHG;
+      int img = row / (TH * TW), ty = (row / TW) % TH, tx = row % TW;
+      int n = img0 + img;
+      if (n >= a.B) return -1;
+      int oy = (KIND == KIND_CONV) ? tyb * TH + ty : 2 * (tyb * TH + ty) + pass;
+      int ox = (KIND == KIND_CONV) ? txb * TW + tx : 2 * (txb * TW + tx) + px;
+      return (((long)n * Hout + oy) * Wout + ox) * COUT;
+    };
+  };
+  constexpr int NIT = (R2 + 256 / (BN / 8) - 1) / (256 / (BN / 8));
+  uint4 yv[(EPI == EPI_MASK) ? 2 : 1][(EPI == EPI_MASK) ? NIT : 1];
+  if constexpr (EPI == EPI_MASK) epi.template load_prev<NIT>(a, n0, R2, rowmap_of(0), yv[0]);
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (EPI == EPI_FWD) bv = *reinterpret_cast<const float4*>(a.bias + n0 + wn * 16 + kgl * 4);
   const int B = a.B;
@@ -458,16 +515,12 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
         st2 = mfma16(fr, fr, st2);
       }
     }
-    auto rowmap = [=](int row2) -> long {
-      const int row = row2 / PHG, px = row2 % PHG;
-      int img = row / (TH * TW), ty = (row / TW) % TH, tx = row % TW;
-      int n = img0 + img;
-      if (n >= B) return -1;
-      int oy = (KIND == KIND_CONV) ? tyb * TH + ty : 2 * (tyb * TH + ty) + pass;
-      int ox = (KIND == KIND_CONV) ? txb * TW + tx : 2 * (txb * TW + tx) + px;
-      return (((long)n * Hout + oy) * Wout + ox) * COUT;
-    };
-    epi.rows(a, tile, n0, R2, rowmap);
+    if constexpr (EPI == EPI_MASK) {
+      if (pass + 1 < NPH / PHG) epi.template load_prev<NIT>(a, n0, R2, rowmap_of(pass + 1), yv[(pass + 1) & 1]);
+      epi.template rows_pre<NIT>(a, tile, n0, R2, rowmap_of(pass), yv[pass & 1]);
+    } else {
+      epi.rows(a, tile, n0, R2, rowmap_of(pass));
+    }
   }
   EAE_STAMP(6);
   if (do_stats) {

@@ -19,10 +19,15 @@ B = 512
 dev = torch.device("cuda:0")
 dbg = torch.zeros(64, dtype=torch.int64, device=dev)
 names = ["loads issued+coef", "transform+LDSwrite", "barrier", "MFMA(last chunk)", "barrier", "tile+rows(all ph)", "stats reduce"]
-for (kind, ci, co, hin) in ((0, 32, 64, 32), (0, 64, 128, 16), (0, 128, 256, 8), (1, 128, 64, 8), (1, 64, 32, 16)):
+CASES = ((0, 32, 64, 32, 1, 0), (0, 64, 128, 16, 1, 0), (0, 128, 256, 8, 1, 0), (1, 128, 64, 8, 1, 0), (1, 64, 32, 16, 1, 0),
+         (1, 64, 32, 16, 2, 1), (0, 32, 64, 32, 2, 1))       # (kind, cin, cout, hin, source mode, epilogue)
+for (kind, ci, co, hin, smode, epi) in CASES:
     x = (torch.randn((B, hin, hin, ci), device=dev) * 0.5).to(torch.bfloat16)
+    x2 = (torch.randn((B, hin, hin, ci), device=dev) * 0.5).to(torch.bfloat16) if smode == 2 else None
     ho = hin // 2 if kind == 0 else hin * 2
     out = torch.empty((B, ho, ho, co), device=dev, dtype=torch.bfloat16)
+    yprev = (torch.randn((B, ho, ho, co), device=dev) * 0.5).to(torch.bfloat16) if epi == 1 else None
+    pcoef = torch.randn((4, co), device=dev) if epi == 1 else None
     w = (torch.randn((co, 9, ci), device=dev) * 0.1).to(torch.bfloat16); bias = torch.randn(co, device=dev)
     nt = lib.eae_op_conv_s2_ntiles(kind, ci, B, hin, hin)
     part = torch.zeros((nt, 2, co), device=dev)
@@ -30,14 +35,15 @@ for (kind, ci, co, hin) in ((0, 32, 64, 32), (0, 64, 128, 16), (0, 128, 256, 8),
     for blk in (0, nt - 1):
         raw.eae_debug_set(C.c_void_p(dbg.data_ptr()), blk)
         for _ in range(3):
-            check(lib.eae_op_conv_s2(G.stream(), kind, G.src(1, x, None, cf), ci, co, B, hin, hin, G.ptr(w), G.ptr(bias), G.ptr(out), G.ptr(part), 0, None, None))
+            check(lib.eae_op_conv_s2(G.stream(), kind, G.src(smode, x, x2, cf), ci, co, B, hin, hin, G.ptr(w), G.ptr(bias), G.ptr(out), G.ptr(part), epi,
+                                     G.ptr(yprev), G.ptr(pcoef)))
         torch.cuda.synchronize()
         t = dbg.cpu().tolist()
         nc = ci // 32
-        msg = [f"kind{kind} {ci}->{co} in{hin} blk {blk}: total {t[7]-t[0]}", f"start->chunk0 stage begin {t[8]-t[0]}"]
+        msg = [f"kind{kind} {ci}->{co} in{hin} src{smode} epi{epi} blk {blk}: total {t[7]-t[0]}", f"start->chunk0 stage begin {t[8]-t[0]}"]
         for c in range(nc):
             b = 8 + c * 4
             nxt = t[8 + (c + 1) * 4] if c + 1 < nc else t[4]
             msg.append(f"c{c}: stage {t[b+1]-t[b]} bar {t[b+2]-t[b+1]} issue {t[b+3]-t[b+2]} mfma(+bar) {nxt-t[b+3]}")
-        msg.append(f"epilogue {t[7]-t[4]}")
+        msg.append(f"epilogue: barrier {t[5]-t[4]} tile+rows {t[6]-t[5]} stats {t[7]-t[6]}")
         print(" | ".join(msg))
