@@ -297,7 +297,10 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->pack = b + o_pack; c->descs_dev = (PackDesc*)(b + o_desc);
   c->dyn = (float*)(b + o_dyn);
   c->sigwords = (unsigned*)(b + o_sig);
-  c->use_gates = getenv("EAE_FORK_EVENTS") == nullptr;
+  // Gate kernels need the kernel they wait for to be able to start while they spin.  rocprofv3's counter collection (--pmc) runs one
+  // kernel at a time on the device: under it (ROCPROF_COUNTER_COLLECTION=1 in the environment) the hand-overs fall back to events.
+  const char* rcc = getenv("ROCPROF_COUNTER_COLLECTION");
+  c->use_gates = getenv("EAE_FORK_EVENTS") == nullptr && !(rcc && atoi(rcc) != 0);
   // hipGraph replay is opt-in (EAE_GRAPH=1): on ROCm 7.2 the replayed graph ran its two branches one after the other
   // (0.80 ms/step) while the eager two-stream launch sequence overlaps them (0.71 ms/step)
   c->use_graph = getenv("EAE_GRAPH") != nullptr && getenv("EAE_NO_GRAPH") == nullptr;

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Per-kernel roofline table (SURVEY.md 8d 'Reporting') from the committed rocprofv3 summaries:
-   profiles/r01_bench_b512_kernel_stats_v<N>.csv (durations) + profiles/r01_pmc_traffic_b512.json (FETCH/WRITE_SIZE).
+   newest profiles/r<NN>_bench_b512_kernel_stats_v<N>.csv (durations) + newest profiles/r<NN>_pmc_traffic_b512.json (FETCH/WRITE_SIZE
+   and the matrix-core busy counters).
    Algorithmic bytes / FLOPs per image follow the minimal-traffic model of SURVEY.md 8d: every logical tensor a kernel must read
    or write counted once (bf16 activations, fp32 input / partial sums), weights excluded (L2-resident, <= 0.6 MB).
-   usage: tools/kernel_report.py [stats.csv] > profiles/r01_per_kernel_roofline.md"""
+   usage: tools/kernel_report.py [stats.csv] > profiles/r02_per_kernel_roofline.md"""
 import csv
 import glob
 import json
@@ -21,10 +22,10 @@ T = [
     ("edge_conv_kernel<0, 0>", "enc.conv1 forward", 4 * X + 2 * Y1, EDGE_MF),
     ("igemm_s2_kernel<0, 32, 64, 64, 16, 8, 1, 1, 0>", "enc.conv2 forward", 2 * Y1 + 2 * Y2, MF),
     ("igemm_s2_kernel<0, 64, 128, 64, 8, 8, 2, 1, 0>", "enc.conv3 forward", 2 * Y2 + 2 * Y3, MF),
-    ("igemm_s2_kernel<0, 128, 256, 64, 4, 4, 8, 1, 0>", "enc.conv4 forward", 2 * Y3 + 2 * Y4, MF),
+    ("s2_kernel<0, 128, 256, 64, 4, 4, 8, 1, 0", "enc.conv4 forward (wave-specialised kernel)", 2 * Y3 + 2 * Y4, MF),
     ("fc_nt_kernel<1, 0>", "enc.fc forward (split-K partials)", 2 * Y4 + 32 * 64 * 4, 2.0 * 4096 * 64 / 1e6),
     ("fc_nt_kernel<3, 1>", "dec.fc forward", 64 * 4 + 2 * Y4, 2.0 * 4096 * 64 / 1e6),
-    ("igemm_s2_kernel<1, 256, 128, 64, 4, 4, 4, 0, 0>", "dec.deconv1 forward", 2 * Y4 + 2 * Y3, MF),
+    ("s2_kernel<1, 256, 128, 64, 4, 4, 4, 0, 0", "dec.deconv1 forward (wave-specialised kernel)", 2 * Y4 + 2 * Y3, MF),
     ("igemm_s2_kernel<1, 128, 64, 64, 8, 8, 1, 1, 0>", "dec.deconv2 forward", 2 * Y3 + 2 * Y2, MF),
     ("igemm_s2_kernel<1, 64, 32, 32, 16, 8, 1, 1, 0>", "dec.deconv3 forward", 2 * Y2 + 2 * Y1, MF),
     ("deconv4_loss_kernel<1>", "dec.deconv4 + sigmoid + MSE + its gradient", 2 * Y1 + 4 * X + 2 * 4 * 64 * 64, EDGE_MF),
@@ -55,17 +56,29 @@ PER_LAUNCH = [      # kernels whose traffic does not scale with the batch: bytes
 ]
 
 
+def newest(pattern, key):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=key)
+    return files[-1] if files else None
+
+
 def main():
-    stats = sys.argv[1] if len(sys.argv) > 1 else sorted(
-        glob.glob(os.path.join(ROOT, "profiles", "r*_bench_b512_kernel_stats_v*.csv")), key=lambda p: int(p.rsplit("_v", 1)[1].split(".")[0]))[-1]
+    import re
+
+    def skey(p):
+        m = re.search(r"r(\d+)_bench_b512_kernel_stats(?:_v(\d+))?\.csv$", p)
+        return (int(m.group(1)), int(m.group(2) or 0))
+    stats = sys.argv[1] if len(sys.argv) > 1 else newest("r*_bench_b512_kernel_stats*.csv", skey)
+    pmc_path = newest("r*_pmc_traffic_b512.json", lambda p: p)
     rows = {r["Name"]: r for r in csv.DictReader(open(stats))}
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_b512.json")))["kernels"]
-    print(f"# Per-kernel roofline, B={B}, one MI355X (`{os.path.relpath(stats, ROOT)}` + `profiles/r01_pmc_traffic_b512.json`)\n")
+    pmc = json.load(open(pmc_path))["kernels"]
+    print(f"# Per-kernel roofline, B={B}, one MI355X (`{os.path.relpath(stats, ROOT)}` + `{os.path.relpath(pmc_path, ROOT)}`)\n")
     print("Durations are rocprofv3 averages inside real train steps (they include the command processor's ≈2–3 µs per dispatch and, for the "
-          "backward kernels, contention with the weight-gradient streams). `alg MB` = algorithmic bytes per launch (SURVEY §8d model), "
-          "`HBM frac` = alg bytes / time / 8 TB/s, `MFMA frac` = FLOPs / time / 2.5 PFLOP/s, `PMC MB` = (2·FETCH_SIZE + WRITE_SIZE) per launch.\n")
-    print("| kernel | role | µs | alg MB | GB/s | HBM frac | TFLOP/s | MFMA frac | PMC MB |")
-    print("|---|---|---|---|---|---|---|---|---|")
+          "backward kernels, contention with the weight-gradient streams that run beside them). `alg MB` = algorithmic bytes per launch "
+          "(SURVEY §8d model), `HBM frac` = alg bytes / time / 8 TB/s, `MFMA frac` = FLOPs / time / 2.5 PFLOP/s, `PMC MB` = "
+          "(2·FETCH_SIZE + WRITE_SIZE) per launch, `MFMA busy` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 · 1024 SIMDs): the fraction "
+          "of the kernel's lifetime in which a SIMD's matrix pipe was busy, averaged over all SIMDs (separate `--pmc` pass).\n")
+    print("| kernel | role | µs | alg MB | GB/s | HBM frac | TFLOP/s | MFMA frac | PMC MB | PMC/alg | MFMA busy |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
 
     def find(frag):
         for n, r in rows.items():
@@ -81,8 +94,12 @@ def main():
         mb = B * bpi / 1e6
         gbs = B * bpi / (us * 1e-6) / 1e9
         tf = B * mf * 1e6 / (us * 1e-6) / 1e12
-        tr = pmc.get(n, {}).get("traffic_bytes")
-        print(f"| `{frag}` | {what} | {us:.1f} | {mb:.1f} | {gbs:.0f} | {gbs / HBM:.2f} | {tf:.0f} | {tf / MFMA:.3f} | {tr / 1e6 if tr else float('nan'):.1f} |")
+        k = pmc.get(n, {})
+        tr = k.get("traffic_bytes")
+        mu = k.get("mfma_util")
+        short = n.split("(")[0].replace("void ", "")
+        print(f"| `{short}` | {what} | {us:.1f} | {mb:.1f} | {gbs:.0f} | {gbs / HBM:.2f} | {tf:.0f} | {tf / MFMA:.3f} | "
+              f"{tr / 1e6 if tr else float('nan'):.1f} | {tr / 1e6 / mb if tr else float('nan'):.2f} | {mu if mu is not None else float('nan'):.3f} |")
     for frag, what, byts in PER_LAUNCH:
         n, r = find(frag)
         if r is None:
@@ -90,10 +107,16 @@ def main():
         us = float(r["AverageNs"]) / 1e3
         gbs = byts / (us * 1e-6) / 1e9
         tr = pmc.get(n, {}).get("traffic_bytes")
-        print(f"| `{frag}` | {what} | {us:.1f} | {byts / 1e6:.1f} | {gbs:.0f} | {gbs / HBM:.2f} | – | – | {tr / 1e6 if tr else float('nan'):.1f} |")
+        print(f"| `{frag}` | {what} | {us:.1f} | {byts / 1e6:.1f} | {gbs:.0f} | {gbs / HBM:.2f} | – | – | {tr / 1e6 if tr else float('nan'):.1f} | – | – |")
     small = [(n, float(r["AverageNs"]) / 1e3, int(r["Calls"])) for n, r in rows.items()
-             if any(k in n for k in ("bn_finalize", "bn_bwd_finalize", "reduce_slices", "fc_splitk_reduce", "head_kernel", "loss_finalize"))]
-    print("\nLatency-bound helpers (no meaningful roofline; per launch): " + "; ".join(f"`{n.split('(')[0]}` {us:.1f} µs" for n, us, _ in sorted(small)))
+             if any(k in n for k in ("bn_finalize", "bn_bwd_finalize", "reduce_slices", "fc_splitk_reduce", "head_kernel", "loss_finalize",
+                                     "gate_kernel", "signal_kernel"))]
+    print("\nLatency-bound helpers (no meaningful roofline; average per launch; `gate_kernel` = a side stream waiting for the main "
+          "stream's progress word, one wave): " + "; ".join(f"`{n.split('(')[0]}` {us:.1f} µs" for n, us, _ in sorted(small)))
+    tot = sum(float(r["TotalDurationNs"]) for n, r in rows.items() if "gate_kernel" not in n)
+    calls = [int(r["Calls"]) for n, r in rows.items() if n.startswith("adam_kernel")]
+    if calls:
+        print(f"\nSum of kernel durations per step (all streams, gates excluded): {tot / calls[0] / 1e3:.0f} µs.")
 
 
 if __name__ == "__main__":

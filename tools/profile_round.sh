@@ -13,6 +13,11 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-roofline --no-configs > $OUT/trace.log 2>&1
+# Counter collection runs ONE kernel at a time on the device: a gate kernel (side stream polling the main stream's progress word)
+# would spin until its bounded time-out while the kernel it waits for cannot start.  The counter passes therefore use event-based
+# hand-overs (EAE_FORK_EVENTS=1: same kernels, same arguments, same per-kernel traffic; exported here, not through an `env` hop).
+export EAE_FORK_EVENTS=1
+python3 -c "import os; print({k: v for k, v in os.environ.items() if 'ROCP' in k.upper()})" > $OUT/env_plain.log 2>&1 || true
 for P in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/$P -o p -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-configs > $OUT/$P.log 2>&1
 done
