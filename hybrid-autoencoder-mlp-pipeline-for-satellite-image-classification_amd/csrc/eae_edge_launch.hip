@@ -34,7 +34,10 @@ int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B
   a.src3 = src3; a.B = B; a.H = H; a.W = W; a.side = side; a.part = scratch;
   a.ntiles = eae_edge_tiles(B, H, W);
   static const int cap = getenv("EAE_EDGE_WGRAD_BLOCKS") ? atoi(getenv("EAE_EDGE_WGRAD_BLOCKS")) : 1024;   // 4 blocks per CU fit: one round of workgroups (0.510-0.514 vs 0.514-0.517 ms per step with 512)
-  int nblocks = a.ntiles < cap ? a.ntiles : cap;
+  // a launch beside the backward-data chain (deconv4's weight gradient, side stream) takes fewer CUs from it with fewer blocks
+  static const int cap_side = getenv("EAE_EDGE_WGRAD_SIDE_BLOCKS") ? atoi(getenv("EAE_EDGE_WGRAD_SIDE_BLOCKS")) : 1024;
+  const int lim = (src3_kind == SRC3_NHWC4_BF16) ? cap_side : cap;
+  int nblocks = a.ntiles < lim ? a.ntiles : lim;
   while ((long long)nblocks * 864 > scratch_floats && nblocks > 1) nblocks /= 2;
   a.tiles_per_block = (a.ntiles + nblocks - 1) / nblocks;
   nblocks = (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;

@@ -1,5 +1,7 @@
 // Host-side dispatch of the generic 3x3 stride-2 weight-gradient kernel.
 #include "eae_internal.h"
+#include <cstdio>
+#include <cstdlib>
 #include "eae_wgrad.hip.h"
 
 namespace {
@@ -8,13 +10,22 @@ int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_fl
   WgradArgs a = a0;
   constexpr int nblk = (CS / 64) * (CB / 32);
   constexpr long long sz = (long long)CS * CB * 9;
-  // One 12-wave workgroup per CU (4 consumer + 8 producer waves).  EAE_WGRAD_WGS workgroups in all: every one writes a partial of
-  // its 64 x 32 x 9 block, so the count also sets the split-K traffic.
-  // The 64x32 layers (one block, 67-84 MB of operands) are bandwidth-bound: every CU.  The wider layers (4 / 16 blocks, 17-42 MB)
-  // are bound by per-workgroup overheads and by the partial writes themselves (256 workgroups = 18.9 MB of partials for 21 MB of
-  // operands): half as many workgroups, twice the tiles each.
-  static const int wgs_env = getenv("EAE_WGRAD_WGS") ? atoi(getenv("EAE_WGRAD_WGS")) : 0;
-  const int wgs = wgs_env ? wgs_env : (nblk == 1 ? 256 : 128);
+  // 12-wave workgroups (4 consumer + 8 producer waves), one per CU.  Every workgroup writes a partial of its 64 x 32 x 9 block, so
+  // their number also sets the split-K traffic and the work of the reduction behind the kernel.  Inside the train step these
+  // kernels run beside the backward-data chain, and what counts is how many CUs they take from it: 64 workgroups measured best for
+  // every layer (ms per step at B=512 / B=64: 32: 0.599 / 0.241, 48: 0.540, 64: 0.500-0.512 / 0.244, 80: 0.515, 128: 0.509-0.527 /
+  // 0.271, 256: 0.542).  EAE_WGRAD_WGS=<n> or <n one-block layers>,<n wider layers> overrides.
+  static int wgs_one = 64, wgs_wide = 64;
+  static const bool parsed = [] {
+    if (const char* e = getenv("EAE_WGRAD_WGS")) {
+      int a = 0, b = 0;
+      const int n = sscanf(e, "%d,%d", &a, &b);
+      if (n >= 1 && a > 0) { wgs_one = a; wgs_wide = (n == 2 && b > 0) ? b : a; }
+    }
+    return true;
+  }();
+  (void)parsed;
+  const int wgs = nblk == 1 ? wgs_one : wgs_wide;
   int slices = wgs / nblk;
   if (slices < 1) slices = 1;
   if (slices > ntiles) slices = ntiles;
