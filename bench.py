@@ -117,6 +117,30 @@ def time_steps(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+def config5_leg(batch=128, steps=20, warmup=5):
+    import eae_amd
+    from eae_amd.engine import AEEngine
+    res = {"workload": "BASELINE configs[4], one GPU's share: 256x256x3 inputs, 256-d latent, joint train step; fp8 = e4m3 weights / "
+                       "activations, e5m2 gradients on v_mfma_f32_16x16x32_{fp8,bf8}_{fp8,bf8} for the six 3x3 layers (delayed scaling), "
+                       "bf16 = the same shape through the bf16 kernels", "per_gpu_batch": batch}
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4321)
+    x = torch.rand((batch, 3, 256, 256), generator=g, device="cuda")
+    y = torch.randint(0, 10, (batch,), generator=g, device="cuda")
+    for quant in ("fp8", "bf16"):
+        torch.manual_seed(0)
+        m = eae_amd.SupervisedAutoencoder(latent_dim=256, num_classes=10, image_size=256).cuda().train()
+        eng = AEEngine(m, max_batch=batch, quant=quant)
+        if quant == "fp8":
+            eng.fp8_calibrate(x, y, ALPHA)
+        sec = time_steps(lambda: eng.train_step(x, y, ALPHA, LR), steps, warmup)
+        res[quant] = {"ms_per_step": round(1e3 * sec, 3), "images_per_s": round(batch / sec, 1),
+                      "final_loss": round(float(eng.loss_last.cpu()[0]), 4)}
+        del eng, m
+        torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +253,12 @@ def main():
                                          "frac_of_hbm_floor": round(b2 / (HBM_PEAK_GBS * 1e3) / (sec * 1e6), 4)}}
             except Exception as e:
                 out["configs"] = {"error": str(e)[:200]}
+            # configs[4]'s per-GPU shape and arithmetic (its 8-GPU form is the driver's): 256x256 inputs, 256-d latent, fp8 operands for
+            # the GEMMs of the six 3x3 layers; the same shape in bf16 beside it.  Not the headline; parity in tests/test_gpu_fp8.py.
+            try:
+                out.setdefault("configs", {})["c5"] = config5_leg()
+            except Exception as e:
+                out.setdefault("configs", {})["c5"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

@@ -14,7 +14,7 @@ vp = C.c_void_p
 
 class EaeConfig(C.Structure):
     _fields_ = [("latent_dim", C.c_int), ("num_classes", C.c_int), ("image_h", C.c_int), ("image_w", C.c_int),
-                ("max_batch", C.c_int)]
+                ("max_batch", C.c_int), ("quant", C.c_int)]
 
 
 class EaeStepIO(C.Structure):
@@ -37,6 +37,8 @@ _PROTOS = {
     "eae_destroy": (C.c_int, [vp]),
     "eae_bind": (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
     "eae_gate_timeouts": (C.c_longlong, [vp]),
+    "eae_fp8_calibrate": (C.c_int, [vp, vp, vp, C.c_int]),
+    "eae_fp8_scales": (C.c_int, [vp, vp]),
     "eae_params_changed": (C.c_int, [vp]),
     "eae_set_adam_step": (C.c_int, [vp, C.c_longlong]),
     "eae_get_adam_step": (C.c_longlong, [vp]),
@@ -65,6 +67,8 @@ _PROTOS = {
     "eae_op_edge_wgrad": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, EaeSrc, vp, C.c_longlong, vp]),
     "eae_op_deconv4_loss": (C.c_int, [vp, EaeSrc, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_float, vp, vp, vp]),
     "eae_op_wgrad_s2": (C.c_int, [vp, EaeSrc, EaeSrc, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_longlong, vp]),
+    "eae_op_wgrad_s2_fp8": (C.c_int, [vp, EaeSrc, EaeSrc, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_longlong, vp, vp]),
+    "eae_op_conv_s2_fp8": (C.c_int, [vp, C.c_int, EaeSrc, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]),
     "eae_op_bn_finalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_longlong, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp]),
     "eae_op_bn_eval_coef": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_float, vp]),
     "eae_op_bn_bwd_finalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_longlong, vp, vp, vp, vp, vp]),

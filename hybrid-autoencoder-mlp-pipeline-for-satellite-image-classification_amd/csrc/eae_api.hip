@@ -48,6 +48,9 @@ int check_cfg(const eae_config* c) {
   if (c->latent_dim <= 0 || c->latent_dim > 256) return eae_set_error(EAE_ERR_ARG, "latent_dim must be in 1..256");
   if (c->num_classes <= 0 || c->num_classes > 16) return eae_set_error(EAE_ERR_ARG, "num_classes must be in 1..16");
   if (c->max_batch <= 0) return eae_set_error(EAE_ERR_ARG, "max_batch must be positive");
+  if (c->quant != 0 && c->quant != 1) return eae_set_error(EAE_ERR_ARG, "quant must be 0 (bf16) or 1 (fp8 conv GEMMs)");
+  if (c->quant == 1 && (c->image_h % 128 || c->image_w % 256))
+    return eae_set_error(EAE_ERR_ARG, "quant=1: the fp8 kernels are built for 16 x 8 tiles on every map (image height % 128 == 0, width % 256 == 0)");
   return 0;
 }
 
@@ -63,6 +66,11 @@ struct eae_ctx {
   bool lpad = false;
   float *gs_encw = nullptr, *gs_encb = nullptr, *gs_decw = nullptr, *gs_head = nullptr, *zstage = nullptr;
   size_t pk_w1p = 0, pk_bep = 0;     // lpad: fp32 copies of classifier.0.weight [128][Lp] and enc.fc.bias [Lp]
+  // fp8 variant of the six 3x3 layers' GEMMs (eae_config::quant = 1, BASELINE config 5): e4m3 weight packs + delayed-scaling state
+  bool fp8 = false;
+  size_t pk8_p1[6] = {}, pk8_p2[6] = {};
+  Fp8State* q = nullptr;
+  float* bn_save = nullptr;          // eae_fp8_calibrate: copy of the running statistics + num_batches_tracked
   long long Pn, K;                 // pixels of the 256-channel map, flattened features
   long long poff[39], bnoff[15];
   float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *bnrun = nullptr;
@@ -252,7 +260,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   std::vector<PackDesc> descs;
   auto add = [&](long long src, size_t dst, long long cnt, int mode, int d0, int d1, int d2, int f32) {
     PackDesc d; d.src_off = src; d.dst_off = (long long)dst; d.count = cnt; d.mode = mode; d.d0 = d0; d.d1 = d1; d.d2 = d2; d.out_f32 = f32;
-    d.lv = d0;
+    d.lv = d0; d.q_layer = -1;
     descs.push_back(d);
   };
   c->pk_c1 = pcarve(32 * 64 * 2); add(c->poff[0], c->pk_c1, 32 * 64, PACK_K36, 32, 3, 0, 0);
@@ -260,7 +268,12 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
     long long n = (long long)W3_A[i] * W3_B[i] * 9;
     c->pk_p1[i] = pcarve(n * 2); add(c->poff[W3_PARAM[i]], c->pk_p1[i], n, PACK_3x3_P1, W3_A[i], W3_B[i], 0, 0);
     c->pk_p2[i] = pcarve(n * 2); add(c->poff[W3_PARAM[i]], c->pk_p2[i], n, PACK_3x3_P2, W3_A[i], W3_B[i], 0, 0);
+    if (cfg->quant == 1) {
+      c->pk8_p1[i] = pcarve(n); add(c->poff[W3_PARAM[i]], c->pk8_p1[i], n, PACK_3x3_P1, W3_A[i], W3_B[i], 0, 0); descs.back().q_layer = i;
+      c->pk8_p2[i] = pcarve(n); add(c->poff[W3_PARAM[i]], c->pk8_p2[i], n, PACK_3x3_P2, W3_A[i], W3_B[i], 0, 0); descs.back().q_layer = i;
+    }
   }
+  c->fp8 = cfg->quant == 1;
   c->pk_d4j = pcarve(16 * 128 * 2); add(c->poff[32], c->pk_d4j, 16 * 128, PACK_DECONV4_JOINT, 0, 0, 0, 0);
   c->pk_d4k = pcarve(32 * 64 * 2); add(c->poff[32], c->pk_d4k, 32 * 64, PACK_K36, 32, 3, 0, 0);
   const long long LK = c->Lp * c->K;      // d0 = padded latent width, lv = the real one (rows / columns beyond it are zero)
@@ -275,7 +288,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   }
   c->pk_bd = pcarve(c->K * 4); add(c->poff[19], c->pk_bd, c->K, PACK_FC_ROWPERM, 1, 256, (int)c->Pn, 1);
   c->ndesc = (int)descs.size();
-  size_t o_pack = carve(poffb), o_desc = carve(descs.size() * sizeof(PackDesc));
+  size_t o_pack = carve(poffb), o_desc = carve(descs.size() * sizeof(PackDesc)), o_q = carve(sizeof(Fp8State)), o_bns = carve(2048 * 4 + 64);
   hipError_t e = hipMalloc(&c->ws, off);
   if (e != hipSuccess) { delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
   uint8_t* b = static_cast<uint8_t*>(c->ws);
@@ -297,6 +310,14 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->pack = b + o_pack; c->descs_dev = (PackDesc*)(b + o_desc);
   c->dyn = (float*)(b + o_dyn);
   c->sigwords = (unsigned*)(b + o_sig);
+  c->q = (Fp8State*)(b + o_q);
+  c->bn_save = (float*)(b + o_bns);
+  {
+    Fp8State h;
+    eae_fp8_state_init(&h);
+    hipError_t eq = hipMemcpy(c->q, &h, sizeof(h), hipMemcpyHostToDevice);
+    if (eq != hipSuccess) { hipFree(c->ws); delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(eq)); }
+  }
   // Gate kernels need the kernel they wait for to be able to start while they spin.  rocprofv3's counter collection (--pmc) runs one
   // kernel at a time on the device: under it (ROCPROF_COUNTER_COLLECTION=1 in the environment) the hand-overs fall back to events.
   const char* rcc = getenv("ROCPROF_COUNTER_COLLECTION");
@@ -587,7 +608,7 @@ int join_side(eae_ctx* c, hipStream_t st) {
 
 int ensure_packed(eae_ctx* c, hipStream_t st) {
   if (c->packed) return 0;
-  RC(eae_launch_pack_all(st, c->descs_dev, c->ndesc, c->P, c->pack));
+  RC(eae_launch_pack_all(st, c->descs_dev, c->ndesc, c->P, c->pack, c->fp8 ? c->q : nullptr));
   c->packed = true;
   return 0;
 }
@@ -598,6 +619,14 @@ SrcDesc src_bnbwd(const bf16_t* g, const bf16_t* y, const float* coef) { SrcDesc
 SrcDesc src_f32(const float* p) { SrcDesc s; s.p0 = reinterpret_cast<const bf16_t*>(p); s.p1 = nullptr; s.coef = nullptr; return s; }
 
 constexpr float ACC_SCALE_FWD = 16777216.f;      // 2^24: sums of y and y^2 over <= 2^21 elements of |y| <~ 1e3 stay far below 2^63
+
+// fp8 variant: weight pack, scales and the amax word of 3x3 layer j (W3 order) for a forward / backward-data launch
+void fp8_conv_args(eae_ctx* c, ConvArgs& a, int j, bool forward, bool p1) {
+  if (!c->fp8) return;
+  a.wpack = (const bf16_t*)(c->pack + (p1 ? c->pk8_p1[j] : c->pk8_p2[j]));
+  a.qs = forward ? c->q->qs_fwd[j] : c->q->qs_bwd[j];
+  a.amax = forward ? &c->q->amax_act[j] : &c->q->amax_grad[j];
+}
 
 // producer side of the folded forward finalize of BN layer l
 void fold_producer(eae_ctx* c, ConvArgs& a, int l, bool train) {
@@ -714,6 +743,7 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
     a.B = B; a.Hin = H >> i; a.Win = W >> i;
     fold_producer(c, a, i, train);
     fold_consumer(c, a.fold, i - 1, (long long)B * a.Hin * a.Win, train);
+    fp8_conv_args(c, a, i - 1, true, true);
     {
       ProfBracket pb(c, i == 1 ? EAE_PROF_CONV2_FWD : -1, st);
       RC(eae_launch_conv_s2(a, ENC_C[i], ENC_C[i + 1], SRC_BNRELU, EPI_FWD, st));
@@ -759,6 +789,7 @@ int run_decoder(eae_ctx* c, hipStream_t st, const float* z, int B, bool train, c
     a.B = B; a.Hin = H >> (4 - i); a.Win = W >> (4 - i);
     fold_producer(c, a, 4 + i, train);
     if (i > 0) fold_consumer(c, a.fold, 3 + i, (long long)B * a.Hin * a.Win, train);
+    fp8_conv_args(c, a, 3 + i, true, false);
     {
       ProfBracket pb(c, i == 2 ? EAE_PROF_DECONV3_FWD : -1, st);
       RC(eae_launch_deconv_s2(a, cin[i], cin[i] / 2, i == 0 ? SRC_RAW : SRC_BNRELU, EPI_FWD, st));
@@ -919,6 +950,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
         w.big = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
         w.B = B; w.Hs = Hs; w.Ws = Ws;
         fold_bwd_consumer(c, w.bfold, 4 + i, (long long)B * (Hs * 2) * (Ws * 2), false);
+        if (c->fp8) w.qs = c->q->qs_wg[3 + i];
         return eae_launch_wgrad_s2(s2, w, cs, cb, i == 0 ? SRC_RAW : SRC_BNRELU, SRC_BNBWD, scr, c->wscratch_floats, c->G + c->poff[20 + 4 * i],
                                    prof_hook_for(c, i == 2 ? EAE_PROF_DECONV3_WGRAD : -1));
       });
@@ -928,6 +960,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
       a.wpack = (const bf16_t*)(c->pack + c->pk_p1[3 + i]);
       a.B = B; a.Hin = Hs * 2; a.Win = Ws * 2;
       fold_bwd_consumer(c, a.bfold, 4 + i, (long long)B * a.Hin * a.Win, true);
+      fp8_conv_args(c, a, 3 + i, false, true);
       take_sig(c, a);
       if (i > 0) {
         a.out = c->gu[i - 1]; a.stat_part = c->stat; a.yprev = c->u[i - 1]; a.prev_coef = c->coef_f[3 + i];
@@ -1014,6 +1047,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
       w.big = src_bnrelu(c->y[i - 1], c->coef_f[i - 1]);
       w.B = B; w.Hs = Hs; w.Ws = Ws;
       fold_bwd_consumer(c, w.bfold, i, (long long)B * Hs * Ws, false);
+      if (c->fp8) w.qs = c->q->qs_wg[i - 1];
       return eae_launch_wgrad_s2(s2, w, cs, cb, SRC_BNBWD, SRC_BNRELU, scr, c->wscratch_floats, c->G + c->poff[4 * i],
                                  prof_hook_for(c, i == 1 ? EAE_PROF_CONV2_WGRAD : -1));
     });
@@ -1025,6 +1059,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     a.B = B; a.Hin = Hs; a.Win = Ws;
     fold_bwd_producer(c, a, i - 1);
     fold_bwd_consumer(c, a.bfold, i, (long long)B * Hs * Ws, true);
+    fp8_conv_args(c, a, i - 1, false, false);
     take_sig(c, a);
     {
       ProfBracket pb(c, i == 1 ? EAE_PROF_CONV2_BWD : -1, st);
@@ -1045,6 +1080,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
   RC(eae_launch_edge_wgrad(st, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, c->wscratch_main,
                            2048LL * 864, c->G + c->poff[0], prof_hook_for(c, EAE_PROF_CONV1_WGRAD), &bf0));
   RC(join_side(c, st));
+  if (c->fp8) RC(eae_launch_fp8_scales(st, c->q));      // every reader of this step's scales has finished: derive the next step's
   // Biases in front of a BatchNorm have an identically zero gradient (the reference computes ~1e-9 rounding noise);
   // their slots in the gradient arena are zeroed once in eae_bind and never written.
   return 0;
@@ -1088,6 +1124,41 @@ extern "C" int eae_ae_grad_step(eae_ctx* c, void* stream, const eae_step_io* io)
   hipStream_t st = (hipStream_t)stream;
   RC(forward_impl(c, st, io, true));
   return backward_impl(c, st, io);
+}
+
+// fp8 variant: settle the delayed scales before the first real step.  Every iteration is a gradient step without the optimizer (the
+// fp8 packs are rebuilt with the current weight scale each time); a scale is right once the tensors upstream of it were computed with
+// right scales, so the backward chain of 6 layers needs 7 iterations.  BatchNorm running statistics and num_batches_tracked are
+// restored afterwards; the gradient arena holds the last iteration's gradients.
+extern "C" int eae_fp8_calibrate(eae_ctx* c, void* stream, const eae_step_io* io, int iters) {
+  RC(check_io(c, io, true));
+  if (!c->fp8) return eae_set_error(EAE_ERR_STATE, "fp8_calibrate: the context was not created with quant = 1");
+  if (iters <= 0) iters = 7;
+  hipStream_t st = (hipStream_t)stream;
+  eae_step_io t = *io;
+  t.x_hat = nullptr; t.logits = nullptr; t.z = nullptr; t.loss_accum = nullptr; t.loss_last = nullptr;
+  const size_t bn_bytes = (size_t)c->bnoff[14] * 4;
+  EAE_HIP(hipMemcpyAsync(c->bn_save, c->bnrun, bn_bytes, hipMemcpyDeviceToDevice, st));
+  if (c->nbt) EAE_HIP(hipMemcpyAsync(c->bn_save + c->bnoff[14], c->nbt, 7 * 8, hipMemcpyDeviceToDevice, st));
+  for (int it = 0; it < iters; ++it) {
+    c->packed = false;
+    RC(forward_impl(c, st, &t, true));
+    RC(backward_impl(c, st, &t));
+  }
+  EAE_HIP(hipMemcpyAsync(c->bnrun, c->bn_save, bn_bytes, hipMemcpyDeviceToDevice, st));
+  if (c->nbt) EAE_HIP(hipMemcpyAsync(c->nbt, c->bn_save + c->bnoff[14], 7 * 8, hipMemcpyDeviceToDevice, st));
+  c->packed = false; c->fwd_ready = false;
+  return 0;
+}
+// current scales: s_act[6], s_grad[6], s_w[6] (3x3 layers in the order conv2, conv3, conv4, deconv1, deconv2, deconv3); synchronises
+extern "C" int eae_fp8_scales(eae_ctx* c, float* out18) {
+  if (!c || !out18) return eae_set_error(EAE_ERR_ARG, "fp8_scales: NULL argument");
+  if (!c->fp8) return eae_set_error(EAE_ERR_STATE, "fp8_scales: the context was not created with quant = 1");
+  EAE_HIP(hipDeviceSynchronize());
+  Fp8State h;
+  EAE_HIP(hipMemcpy(&h, c->q, sizeof(h), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 6; ++i) { out18[i] = h.s_act[i]; out18[6 + i] = h.s_grad[i]; out18[12 + i] = h.s_w[i]; }
+  return 0;
 }
 
 extern "C" int eae_adam_step(eae_ctx* c, void* stream, float lr, float weight_decay) {
@@ -1245,6 +1316,19 @@ extern "C" int eae_op_conv_s2(void* stream, int kind, eae_src src, int cin, int 
   return eae_launch_deconv_s2(a, cin, cout, src.mode, epilogue, (hipStream_t)stream);
 }
 extern "C" int eae_op_conv_s2_ntiles(int kind, int cin, int B, int Hin, int Win) { return eae_conv_s2_ntiles(kind, B, Hin, Win, cin); }
+// fp8 variant of the same op (16 x 8-tileable maps only): wpack = e4m3 bytes [cout][9][cin] of w * s_w;  qs (device) = {1/s_pixel,
+// 1/(s_pixel * s_w)};  amax (device, may be NULL) receives max |staged pixel operand| as float bits (atomicMax)
+extern "C" int eae_op_conv_s2_fp8(void* stream, int kind, eae_src src, int cin, int cout, int B, int Hin, int Win, const void* wpack_e4m3,
+                                  const float* bias, void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef,
+                                  const float* qs, unsigned* amax) {
+  if (!qs) return eae_set_error(EAE_ERR_ARG, "conv_s2_fp8: qs is NULL");
+  ConvArgs a = ConvArgs();
+  a.src = to_src(src); a.wpack = (const bf16_t*)wpack_e4m3; a.bias = bias; a.out = (bf16_t*)out; a.stat_part = stat_part;
+  a.yprev = (const bf16_t*)yprev; a.prev_coef = prev_coef; a.B = B; a.Hin = Hin; a.Win = Win;
+  a.qs = qs; a.amax = amax;
+  if (kind == 0) return eae_launch_conv_s2(a, cin, cout, src.mode, epilogue, (hipStream_t)stream);
+  return eae_launch_deconv_s2(a, cin, cout, src.mode, epilogue, (hipStream_t)stream);
+}
 
 extern "C" int eae_op_edge_conv(void* stream, int src3_kind, const void* src3, int B, int H, int W, const void* wpack, const float* bias,
                                 void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef) {
@@ -1270,6 +1354,14 @@ extern "C" int eae_op_wgrad_s2(void* stream, eae_src small_src, eae_src big_src,
                                long long scratch_floats, float* dw) {
   WgradArgs w = WgradArgs();
   w.small = to_src(small_src); w.big = to_src(big_src); w.B = B; w.Hs = Hs; w.Ws = Ws;
+  return eae_launch_wgrad_s2((hipStream_t)stream, w, cs, cb, small_src.mode, big_src.mode, scratch, scratch_floats, dw);
+}
+// fp8 variant: qs (device) = {1/s_small, 1/s_big, 1/(s_small * s_big)}; the SRC_BNBWD operand is converted to e5m2, the other to e4m3
+extern "C" int eae_op_wgrad_s2_fp8(void* stream, eae_src small_src, eae_src big_src, int cs, int cb, int B, int Hs, int Ws, float* scratch,
+                                   long long scratch_floats, float* dw, const float* qs) {
+  if (!qs) return eae_set_error(EAE_ERR_ARG, "wgrad_s2_fp8: qs is NULL");
+  WgradArgs w = WgradArgs();
+  w.small = to_src(small_src); w.big = to_src(big_src); w.B = B; w.Hs = Hs; w.Ws = Ws; w.qs = qs;
   return eae_launch_wgrad_s2((hipStream_t)stream, w, cs, cb, small_src.mode, big_src.mode, scratch, scratch_floats, dw);
 }
 extern "C" int eae_op_bn_finalize(void* stream, const float* stat_part, int ntiles, int C, long long count, const float* gamma,
@@ -1342,8 +1434,8 @@ extern "C" int eae_op_pack3x3(void* stream, const float* w, int A, int B, void* 
   // one-off helper for tests: builds a 2-entry descriptor table on the fly (synchronous upload)
   PackDesc d[2];
   long long n = (long long)A * B * 9;
-  d[0] = PackDesc{0, 0, n, PACK_3x3_P1, A, B, 0, 0};
-  d[1] = PackDesc{0, (long long)((char*)p2 - (char*)p1), n, PACK_3x3_P2, A, B, 0, 0};
+  d[0] = PackDesc{0, 0, n, PACK_3x3_P1, A, B, 0, 0, 0, -1};
+  d[1] = PackDesc{0, (long long)((char*)p2 - (char*)p1), n, PACK_3x3_P2, A, B, 0, 0, 0, -1};
   PackDesc* dev = nullptr;
   EAE_HIP(hipMalloc(&dev, sizeof(d)));
   EAE_HIP(hipMemcpy(dev, d, sizeof(d), hipMemcpyHostToDevice));

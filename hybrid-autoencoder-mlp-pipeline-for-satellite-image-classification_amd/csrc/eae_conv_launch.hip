@@ -22,6 +22,21 @@ int launch(const ConvArgs& a, hipStream_t st) {   // NOLINT
   return 0;
 }
 
+// fp8 variant (BASELINE config 5): same geometry, operands converted to fp8 (ConvArgs::qs set by the engine); 16-wide tiles only
+template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
+int launch8(const ConvArgs& a, hipStream_t st) {   // NOLINT
+  auto kern = igemm8_s2_kernel<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI>;
+  constexpr size_t smem = igemm_smem<KIND, BN, TW, TH, NI>();
+  EAE_HIP(eae_smem_attr(reinterpret_cast<const void*>(kern), smem));
+  const int Hpos = (KIND == KIND_CONV) ? a.Hin / 2 : a.Hin, Wpos = (KIND == KIND_CONV) ? a.Win / 2 : a.Win;
+  const int ntiles = a.B * (Hpos / TH) * (Wpos / TW);
+  ConvArgs b = a;
+  b.ntiles = ntiles;
+  hipLaunchKernelGGL(kern, dim3(ntiles * (COUT / BN)), dim3(256), smem, st, b);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+
 // Wave-specialised kernel (eae_igemm2.hip.h) for the multi-chunk layers on the small maps.  Inside the training step (rocprofv3,
 // B=512, us, igemm2 vs one-role kernel): conv 128->256 forward 16.7 vs 18.3 and deconv 256->128 forward 16.5 vs 18.2 win; conv
 // 64->128 forward 18.5 vs 16.8, deconv 128->64 forward 22.6 vs 19.6, and every backward-data use (31.3 vs 26.2, 48.8 vs 33.6: a
@@ -70,7 +85,9 @@ static bool deconv_small(int B, int Win, int cout) {
 template <int CIN, int COUT, int BN, int SRC, int EPI>
 int conv_geo(const ConvArgs& a, hipStream_t st) {
   const int Hp = a.Hin / 2, Wp = a.Win / 2;
-  if (Wp % 16 == 0 && Hp % 8 == 0) return launch<KIND_CONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st);
+  if (Wp % 16 == 0 && Hp % 8 == 0)
+    return a.qs ? launch8<KIND_CONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st) : launch<KIND_CONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st);
+  if (a.qs) return eae_set_error(-2, "conv_s2: the fp8 variant needs output maps that are multiples of 8 x 16");
   if constexpr (CIN >= 64) {
     constexpr int NBL = (CIN == 64) ? COUT / BN : 1;       // two chunks: both stay resident, the workgroup loops over the channel blocks
     const bool small = (Wp == 8 || Wp == 4) && conv_small(a.B, Wp, COUT);
@@ -97,7 +114,9 @@ int deconv_geo(const ConvArgs& a, hipStream_t st) {
   if constexpr (CIN == 64) {
     if (a.Win % 16 == 0 && a.Hin % 4 == 0 && deconv64_th4()) return launch<KIND_DECONV, CIN, COUT, BN, 16, 4, 1, SRC, EPI>(a, st);
   }
-  if (a.Win % 16 == 0 && a.Hin % 8 == 0) return launch<KIND_DECONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st);
+  if (a.Win % 16 == 0 && a.Hin % 8 == 0)
+    return a.qs ? launch8<KIND_DECONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st) : launch<KIND_DECONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st);
+  if (a.qs) return eae_set_error(-2, "deconv_s2: the fp8 variant needs input maps that are multiples of 8 x 16");
   if constexpr (CIN >= 128) {
     if (igemm2_on<KIND_DECONV, CIN, EPI>()) {
       if (a.Win == 8 && a.Hin == 8) return launch2<KIND_DECONV, CIN, COUT, BN, 8, 8, 1, SRC, EPI, 1>(a, st);

@@ -40,6 +40,12 @@ struct ConvArgs {
   BnAcc bacc;              // statistics go to fixed-point accumulators instead of stat_part (finalize folded into the consumer)
   BnFold fold;             // SRC_BNRELU: build the source layer's coefficient table from its accumulators
   BnBwdFold bfold;         // SRC_BNBWD: build the source layer's backward coefficient table from its accumulators
+  // fp8 variant (igemm8_s2_kernel, BASELINE config 5): wpack = e4m3 bytes [COUT][9][CIN];  qs[0] = 1 / (scale of the pixel
+  // operand) -- the fragments are converted bf16 -> e4m3 (activations) / e5m2 (gradients) with v_cvt_scalef32_pk_*_bf16, which
+  // DIVIDES by its scale operand --, qs[1] = 1 / (pixel scale * weight scale), applied to the accumulators;  amax: the largest
+  // |staged value| (bf16 bits << 16, atomicMax) for the next step's scale (delayed scaling, eae_fp8.hip)
+  const float* qs;
+  unsigned* amax;
 #ifdef EAE_STAMPS
   unsigned long long* dbg; // diagnostic build only: s_memtime stamps of workgroup `dbg_block`, wave 0
   int dbg_block;
@@ -239,8 +245,43 @@ struct Geo {
 // A 64-position tile of the transposed kind (2 m-tiles x 4 phases of accumulators per wave) fits the budget of 4 per CU as well.
 constexpr int ig_occ(int kind, int cin, int cout, int P = 128) { return cin > 64 ? 1 : (cin * cout > 2048 ? 2 : ((kind == 0 || P == 64) ? 4 : 3)); }
 
-template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
-__global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void igemm_s2_kernel(ConvArgs a) {
+// fp8 helpers (lane maps of the fp8 MFMA forms = the bf16 form's, conversion semantics and saturation: tools/probe/probe_fp8.hip)
+template <bool E5M2>
+__device__ __forceinline__ long cvt8(const bf16x8& v, float inv_scale) {
+  s16x2 lo = {0, 0}, hi = {0, 0};
+  const bf16x2 p0 = {v[0], v[1]}, p1 = {v[2], v[3]}, p2 = {v[4], v[5]}, p3 = {v[6], v[7]};
+  if (E5M2) {
+    lo = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(lo, p0, inv_scale, false);
+    lo = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(lo, p1, inv_scale, true);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(hi, p2, inv_scale, false);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(hi, p3, inv_scale, true);
+  } else {
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, p0, inv_scale, false);
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, p1, inv_scale, true);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, p2, inv_scale, false);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, p3, inv_scale, true);
+  }
+  union { s16x2 h[2]; long l; } u;
+  u.h[0] = lo; u.h[1] = hi;
+  return u.l;
+}
+// MODE.FP16_OVFL: out-of-range fp8 conversions clamp to +-max instead of producing NaN
+__device__ __forceinline__ void fp8_saturate_mode() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+// running max of |bf16| over the dwords of a staged piece (two packed 16-bit lanes)
+__device__ __forceinline__ uint32_t amax_pk(uint32_t run, const uint4& o) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  u16x2 r = __builtin_bit_cast(u16x2, run);
+  r = __builtin_elementwise_max(r, __builtin_bit_cast(u16x2, o.x & 0x7fff7fffu));
+  r = __builtin_elementwise_max(r, __builtin_bit_cast(u16x2, o.y & 0x7fff7fffu));
+  r = __builtin_elementwise_max(r, __builtin_bit_cast(u16x2, o.z & 0x7fff7fffu));
+  r = __builtin_elementwise_max(r, __builtin_bit_cast(u16x2, o.w & 0x7fff7fffu));
+  return __builtin_bit_cast(uint32_t, r);
+}
+
+// Q = 0: bf16 operands;  Q = 1: fp8 operands (weights e4m3 from an fp8 pack, pixel fragments converted in registers from the bf16
+// patch: e4m3 for activations, e5m2 for SRC_BNBWD gradients), fp32 accumulation either way
+template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI, int Q>
+__device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   using G = Geo<KIND, TW, TH, NI>;
   static_assert(G::P == 64 || G::P == 128, "tile must hold 64 or 128 positions");
   static_assert(CIN % 32 == 0 && COUT % BN == 0 && (BN == 32 || BN == 64), "shape");
@@ -250,6 +291,14 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
   constexpr int NPA = (NPIX * 4 + 255) / 256;       // 16-byte patch pieces per thread
   constexpr int TS = BN + 8;
   constexpr bool ROWSWEEP = (TW == 16 && NI == 1);      // m-tile == one tile row: sweep the patch rows (see the MFMA loop)
+  static_assert(Q == 0 || ROWSWEEP, "the fp8 variant is built for the 16-wide tiles only");
+  constexpr bool QG = (SRC == SRC_BNBWD);               // fp8 variant: the pixel operand is a gradient -> e5m2
+  if (Q) fp8_saturate_mode();
+  const float q_inv = Q ? a.qs[0] : 1.f;
+  float q_out = Q ? a.qs[1] : 1.f;
+  asm volatile("" : "+v"(q_out));                 // its own register, not the high half of the (q_inv, q_out) load
+  const f32x2 q_out2 = {q_out, q_out};
+  uint32_t amax_run = 0;
   constexpr int PFB = ig_occ(KIND, CIN, COUT, G::P) >= 4 ? 1 : 2;   // pixel-fragment register buffers (double buffering costs 4*MT VGPRs)
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
   bf16_t* patch = smem;                             // [NPIX][PIX_STRIDE]; reused as the output tile [P][TS] + reduction scratch
@@ -294,6 +343,7 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
   const int kgs = tid & 3;          // k-group staged by this thread (256 % 4 == 0 -> fixed per thread)
   // this lane's weight-fragment row: output channel n0 + wn*16 + (lane&15), 8 input channels kgl*8..
   const bf16_t* wrow = a.wpack + (size_t)(n0 + wn * 16 + (lane & 15)) * 9 * CIN + kgl * 8;
+  const uint8_t* wrow8 = reinterpret_cast<const uint8_t*>(a.wpack) + (size_t)(n0 + wn * 16 + (lane & 15)) * 9 * CIN + kgl * 8;
   SrcRsrc rs;
   rs.init<SRC>(a.src);
 
@@ -324,6 +374,7 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
   // of chunk c (register double-buffering), so their latency hides behind the matrix pipe; the 9 weight fragments of chunk
   // c+1 are requested right after chunk c's last MFMA (into the same registers) and arrive while the patch is being staged.
   bf16x8 wf[9];
+  long wq[9];
   RawPiece<SRC> raw[NPA];
   ChanCoef<SRC> cc;
   // prefetch requests are issued in NOFF slices, one after each offset's MFMA group, so that the vector-memory pipe
@@ -342,7 +393,10 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
   };
   auto load_w = [&](int chunk) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) wf[tap] = *reinterpret_cast<const bf16x8*>(wrow + tap * CIN + chunk * 32);
+    for (int tap = 0; tap < 9; ++tap) {
+      if (Q) wq[tap] = *reinterpret_cast<const long*>(wrow8 + tap * CIN + chunk * 32);
+      else wf[tap] = *reinterpret_cast<const bf16x8*>(wrow + tap * CIN + chunk * 32);
+    }
   };
   // accumulator loads first, then the first chunk's weight / patch loads: the table is built while those are in flight
   BnFoldRegs fr;
@@ -380,8 +434,11 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       int q = tid + i * 256;
-      if (q < NPIX * 4)
-        *reinterpret_cast<uint4*>(patch + loff[i]) = transform_piece<SRC>(raw[i], val[i], cc);
+      if (q < NPIX * 4) {
+        const uint4 o = transform_piece<SRC>(raw[i], val[i], cc);
+        if (Q) amax_run = amax_pk(amax_run, o);
+        *reinterpret_cast<uint4*>(patch + loff[i]) = o;
+      }
     }
     EAE_STAMP(8 + chunk * 4 + 1);
     __syncthreads();
@@ -408,15 +465,21 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
         // their MFMAs (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma: a full LDS round trip per MFMA, seen in the ISA of several instances)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int cx = 0; cx < G::NKX; ++cx)
+        for (int cx = 0; cx < G::NKX; ++cx) {
+          long rq = 0;
+          if (Q) rq = cvt8<QG>(rf[R & 1][cx], q_inv);       // 4 conversions per fragment, each fragment feeds 2-4 MFMAs
 #pragma unroll
           for (int tap = 0; tap < 9; ++tap) {
             constexpr int dummy = 0; (void)dummy;
             const int o = G::tap_off(tap), ry = G::off_row(o);
             if (G::off_col(o) != cx || R < ry || (R - ry) % G::MUL != 0 || (R - ry) / G::MUL >= MT) continue;
             const int mi = (R - ry) / G::MUL;
-            acc[G::tap_phase(tap)][mi] = mfma16(wf[tap], rf[R & 1][cx], acc[G::tap_phase(tap)][mi]);
+            f32x4& d = acc[G::tap_phase(tap)][mi];
+            if (Q) d = QG ? __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(wq[tap], rq, d, 0, 0, 0)
+                          : __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wq[tap], rq, d, 0, 0, 0);
+            else d = mfma16(wf[tap], rf[R & 1][cx], d);
           }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (chunk + 1 < NC && R < G::NOFF) issue_slice(chunk + 1, R);
       }
@@ -499,8 +562,14 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
       for (int mi = 0; mi < MT; ++mi) {
         int row = (wm * MT + mi) * 16 + (lane & 15);
         uint2 w2;
+        if (Q) {      // (the scale as an explicit register pair: a packed multiply whose LOW lane reads the HIGH half of a
+                      //  (q_inv, q_out) pair is the op_sel form tests/test_isa_guard.py forbids)
+          w2.x = pk2((f32x2){acc[ph][mi][0], acc[ph][mi][1]} * q_out2 + (f32x2){bv.x, bv.y});
+          w2.y = pk2((f32x2){acc[ph][mi][2], acc[ph][mi][3]} * q_out2 + (f32x2){bv.z, bv.w});
+        } else {
         w2.x = pk2((f32x2){acc[ph][mi][0] + bv.x, acc[ph][mi][1] + bv.y});
         w2.y = pk2((f32x2){acc[ph][mi][2] + bv.z, acc[ph][mi][3] + bv.w});
+        }
         if (NI > 1 && img0 + row / (TH * TW) >= B) w2 = make_uint2(0, 0);   // images past the batch must not enter the statistics
         *reinterpret_cast<uint2*>(tile + (row * PHG + px) * TS + wn * 16 + kgl * 4) = w2;
       }
@@ -537,8 +606,24 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
     }
   }
   epi.end(a, red, n0, tile_id);
+  if (Q && a.amax != nullptr && nblk == 0) {      // the channel blocks of a tile stage the same patch: one of them reports
+    const uint32_t m16 = (amax_run & 0xffffu) > (amax_run >> 16) ? (amax_run & 0xffffu) : (amax_run >> 16);
+    uint32_t wmax = m16;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o = __shfl_xor(wmax, sh); wmax = o > wmax ? o : wmax; }
+    if (lane == 0 && wmax != 0) atomicMax(a.amax, wmax << 16);
+  }
   EAE_STAMP(7);
   EAE_STAMP_WG(1);
+}
+
+template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
+__global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void igemm_s2_kernel(ConvArgs a) {
+  igemm_body<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI, 0>(a);
+}
+template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
+__global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void igemm8_s2_kernel(ConvArgs a) {
+  igemm_body<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI, 1>(a);
 }
 
 template <int KIND, int BN, int TW, int TH, int NI>

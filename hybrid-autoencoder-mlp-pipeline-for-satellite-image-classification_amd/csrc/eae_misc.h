@@ -12,7 +12,22 @@ struct PackDesc {
   int mode, d0, d1, d2;
   int out_f32;         // 1: destination is fp32 (permuted biases), 0: bf16
   int lv;              // FC modes / PACK_PAD_COLS: number of REAL entries along the latent dimension d0 (the rest of d0 is zero padding)
+  int q_layer;         // >= 0: destination is e4m3 bytes scaled by the weight scale of 3x3 layer q_layer (fp8 variant, Fp8State below)
 };
+
+// fp8 variant (BASELINE config 5) -- delayed scaling state in device memory, one per context.  Index i = 3x3 layer in W3 order
+// (conv2, conv3, conv4, deconv1, deconv2, deconv3).  A scale MULTIPLIES a value before its conversion to fp8.
+struct Fp8State {
+  unsigned amax_act[6];    // largest |input activation operand| of layer i seen by this step's forward kernel (bf16 bits << 16)
+  unsigned amax_grad[6];   // largest |output-gradient operand| of layer i seen by this step's backward-data kernel
+  unsigned amax_w[6];      // largest |weight| of layer i seen by this step's pack kernel
+  float s_act[6], s_grad[6], s_w[6];
+  float qs_fwd[6][2];      // ConvArgs::qs of the forward kernel:        1/s_act,  1/(s_act*s_w)
+  float qs_bwd[6][2];      // ConvArgs::qs of the backward-data kernel:  1/s_grad, 1/(s_grad*s_w)
+  float qs_wg[6][4];       // WgradArgs::qs: 1/s_small, 1/s_big, 1/(s_small*s_big)
+};
+void eae_fp8_state_init(Fp8State* host);
+int eae_launch_fp8_scales(hipStream_t st, Fp8State* q);
 
 int eae_launch_bn_finalize(hipStream_t st, const float* part, int ntiles, int C, long long count, const float* gamma,
                            const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef);
@@ -26,7 +41,7 @@ int eae_launch_bn_bwd_coef(hipStream_t st, const double* sums, int C, long long 
 struct GateArgs { unsigned* word[4]; unsigned want[4]; int n; unsigned* timeout; };
 int eae_launch_gate(hipStream_t st, const GateArgs& g);
 int eae_launch_signal(hipStream_t st, unsigned* word, unsigned val);
-int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base);
+int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base, Fp8State* q = nullptr);
 int eae_launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
                     double eps, double wd, long long step);
 int eae_launch_adam_dyn(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double b1, double b2, double eps,

@@ -263,10 +263,24 @@ __device__ __forceinline__ float pack_fetch(const PackDesc& d, const float* __re
 }
 
 __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc* __restrict__ descs, const float* __restrict__ params,
-                                                        uint8_t* __restrict__ pack_base) {
+                                                        uint8_t* __restrict__ pack_base, Fp8State* __restrict__ q) {
   const PackDesc d = descs[blockIdx.y];
   const float* src = params + d.src_off;
   const unsigned count = (unsigned)d.count;
+  if (d.q_layer >= 0) {        // e4m3 bytes = sat(w * s_w); also reports max |w| for the next step's scale (delayed scaling)
+    const float sw = q->s_w[d.q_layer];
+    float mx = 0.f;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+      const float v = pack_fetch(d, src, i);
+      mx = fmaxf(mx, fabsf(v));
+      const float sv = fminf(fmaxf(v * sw, -448.f), 448.f);
+      pack_base[d.dst_off + i] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(sv, 0.f, 0, false) & 0xff);
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&q->amax_w[d.q_layer], __float_as_uint(mx));
+    return;
+  }
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
     float v = pack_fetch(d, src, i);
     if (d.out_f32) reinterpret_cast<float*>(pack_base + d.dst_off)[i] = v;
@@ -274,10 +288,51 @@ __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc*
   }
 }
 
-int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base) {
-  hipLaunchKernelGGL(pack_all_kernel, dim3(256, ndesc), dim3(256), 0, st, descs_dev, params, (uint8_t*)pack_base);
+int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base, Fp8State* q) {
+  hipLaunchKernelGGL(pack_all_kernel, dim3(256, ndesc), dim3(256), 0, st, descs_dev, params, (uint8_t*)pack_base, q);
   EAE_LAUNCH_CHECK();
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp8 variant: delayed scaling.  Once per step (after every kernel that reads the current scales has finished) the scales of
+// the NEXT step are derived from the maxima this step's kernels reported:  s = 2^floor(log2(MAX / (2 * amax)))  (a factor 2 of
+// head room because the operand of the next step is not the one measured), MAX = 448 (e4m3: activations, weights) or 57344
+// (e5m2: gradients).  A tensor whose maximum is 0 or not finite keeps its scale.  The maxima are cleared for the next step.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fp8_scale_from(unsigned amax_bits, float maxv, float keep) {
+  const float amax = __uint_as_float(amax_bits);
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return keep;
+  const float e = floorf(log2f(maxv / (2.f * amax)));
+  return exp2f(fminf(fmaxf(e, -60.f), 60.f));
+}
+__global__ EAE_NO_PK void fp8_scales_kernel(Fp8State* q) {
+  const int i = threadIdx.x;
+  if (i < 6) {
+    q->s_act[i] = fp8_scale_from(q->amax_act[i], 448.f, q->s_act[i]);
+    q->s_grad[i] = fp8_scale_from(q->amax_grad[i], 57344.f, q->s_grad[i]);
+    q->s_w[i] = fp8_scale_from(q->amax_w[i], 448.f, q->s_w[i]);
+    q->amax_act[i] = 0; q->amax_grad[i] = 0; q->amax_w[i] = 0;
+    const float sa = q->s_act[i], sg = q->s_grad[i], sw = q->s_w[i];
+    q->qs_fwd[i][0] = 1.f / sa; q->qs_fwd[i][1] = 1.f / (sa * sw);
+    q->qs_bwd[i][0] = 1.f / sg; q->qs_bwd[i][1] = 1.f / (sg * sw);
+    // weight gradient: conv layers (i < 3): small operand = output gradient, big = input activation; transposed layers: the reverse
+    const float ss = i < 3 ? sg : sa, sb = i < 3 ? sa : sg;
+    q->qs_wg[i][0] = 1.f / ss; q->qs_wg[i][1] = 1.f / sb; q->qs_wg[i][2] = 1.f / (ss * sb); q->qs_wg[i][3] = 0.f;
+  }
+}
+int eae_launch_fp8_scales(hipStream_t st, Fp8State* q) {
+  hipLaunchKernelGGL(fp8_scales_kernel, dim3(1), dim3(64), 0, st, q);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+void eae_fp8_state_init(Fp8State* h) {
+  *h = Fp8State();
+  for (int i = 0; i < 6; ++i) {
+    h->s_act[i] = h->s_grad[i] = h->s_w[i] = 1.f;
+    h->qs_fwd[i][0] = h->qs_fwd[i][1] = h->qs_bwd[i][0] = h->qs_bwd[i][1] = 1.f;
+    h->qs_wg[i][0] = h->qs_wg[i][1] = h->qs_wg[i][2] = 1.f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -36,6 +36,7 @@ struct WgradArgs {
   int B, Hs, Ws;          // small-map spatial size (big map = 2Hs x 2Ws)
   int tiles_per_block, ntiles, nslices;
   BnBwdFold bfold;        // the SRC_BNBWD operand's coefficient table from the layer's backward accumulators (eae_common.hip.h)
+  const float* qs;        // fp8 variant (wgrad8_s2_kernel): 1/scale of the small operand, 1/scale of the big operand, 1/(product)
 };
 
 constexpr int S_STRIDE = 72;   // bf16 elements per staged S row: 64 channels + 8 pad (144 B)
@@ -61,9 +62,14 @@ struct WgRaw {
   bool bval[NPA], sval[2];
 };
 
-template <int CS, int CB, int TW, int TH, int NI, int SMODE, int BMODE>
-__global__ __launch_bounds__(WG_THREADS, 3) void wgrad_s2_kernel(WgradArgs a) {
+// Q = 1: both fragment operands converted in registers to fp8 right before the MFMA (e5m2 for the SRC_BNBWD gradient operand, e4m3
+// for the activation operand), accumulators rescaled in the epilogue (see igemm_body, eae_igemm.hip.h)
+template <int CS, int CB, int TW, int TH, int NI, int SMODE, int BMODE, int Q>
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   static_assert(NI * TH * TW == 128, "tile must hold 128 positions");
+  constexpr bool SG = (SMODE == SRC_BNBWD), BG = (BMODE == SRC_BNBWD);
+  if (Q) fp8_saturate_mode();
+  const float q_s = Q ? a.qs[0] : 1.f, q_b = Q ? a.qs[1] : 1.f, q_out = Q ? a.qs[2] : 1.f;
   static_assert(CS % 64 == 0 && CB % 32 == 0, "shape");
   using G = WgGeo<TW, TH, NI>;
   constexpr int PH = G::PH, PW = G::PW, NPIX = G::NPIX, NPA = G::NPA;
@@ -206,15 +212,28 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_s2_kernel(WgradArgs a) {
         constexpr int dummy = 0; (void)dummy;
         const int pk = ((ks * 32) / (TH * TW) * PH + 2 * (((ks * 32) / TW) % TH)) * PW + 2 * ((ks * 32) % TW);   // pix_of(32*ks), compile time
         bf16x8 sa[2];
+        long sq[2] = {0, 0};
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < 2; ++ii) {
           sa[ii] = tr_frag(sl + s_lo + ks * 32 * S_STRIDE + ii * 16, sl + s_hi + ks * 32 * S_STRIDE + ii * 16);
+          if (Q) sq[ii] = cvt8<SG>(sa[ii], q_s);
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           const int toff = (tap / 3) * PW + (tap % 3);
           bf16x8 bb = tr_frag(patch + p_lo + (pk + toff) * PIX_STRIDE, patch + p_hi + (pk + toff) * PIX_STRIDE);
-          acc[tap][0] = mfma16(sa[0], bb, acc[tap][0]);
-          acc[tap][1] = mfma16(sa[1], bb, acc[tap][1]);
+          if (Q) {
+            const long bq = cvt8<BG>(bb, q_b);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+              acc[tap][ii] = SG ? (BG ? __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(sq[ii], bq, acc[tap][ii], 0, 0, 0)
+                                      : __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(sq[ii], bq, acc[tap][ii], 0, 0, 0))
+                                : (BG ? __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(sq[ii], bq, acc[tap][ii], 0, 0, 0)
+                                      : __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(sq[ii], bq, acc[tap][ii], 0, 0, 0));
+          } else {
+            acc[tap][0] = mfma16(sa[0], bb, acc[tap][0]);
+            acc[tap][1] = mfma16(sa[1], bb, acc[tap][1]);
+          }
         }
       }
     };
@@ -235,7 +254,7 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_s2_kernel(WgradArgs a) {
       for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          ep[((it0 + ii) * 16 + (lane >> 4) * 4 + r) * WG_EP_STRIDE + ecb + tap] = acc[tap][ii][r];
+          ep[((it0 + ii) * 16 + (lane >> 4) * 4 + r) * WG_EP_STRIDE + ecb + tap] = Q ? acc[tap][ii][r] * q_out : acc[tap][ii][r];
     __syncthreads();
   }
   // ---- whole 1152-byte rows of the partial go out with 16-byte stores, already in the reference layout
@@ -246,6 +265,15 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_s2_kernel(WgradArgs a) {
     const int row = e / 72, c4 = e % 72;
     *reinterpret_cast<float4*>(out + (size_t)row * (CB * 9) + c4 * 4) = *reinterpret_cast<const float4*>(ep + row * WG_EP_STRIDE + c4 * 4);
   }
+}
+
+template <int CS, int CB, int TW, int TH, int NI, int SMODE, int BMODE>
+__global__ __launch_bounds__(WG_THREADS, 3) void wgrad_s2_kernel(WgradArgs a) {
+  wgrad_body<CS, CB, TW, TH, NI, SMODE, BMODE, 0>(a);
+}
+template <int CS, int CB, int TW, int TH, int NI, int SMODE, int BMODE>
+__global__ __launch_bounds__(WG_THREADS, 3) void wgrad8_s2_kernel(WgradArgs a) {
+  wgrad_body<CS, CB, TW, TH, NI, SMODE, BMODE, 1>(a);
 }
 
 // Deterministic slice reductions: block = 16 float4 lanes x 16 slice lanes; every thread sums its slices in order, then

@@ -36,8 +36,12 @@ int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_fl
   slices = (ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
   a.part = scratch;
   a.nslices = slices;
-  auto kern = wgrad_s2_kernel<CS, CB, TW, TH, NI, SM, BM>;
   constexpr size_t smem = WgGeo<TW, TH, NI>::smem();
+  void (*kern)(WgradArgs) = wgrad_s2_kernel<CS, CB, TW, TH, NI, SM, BM>;
+  if (a.qs) {                                // fp8 variant (BASELINE config 5): built for the 16 x 8 tiles only
+    if constexpr (TW == 16) kern = wgrad8_s2_kernel<CS, CB, TW, TH, NI, SM, BM>;
+    else return eae_set_error(-2, "wgrad: the fp8 variant needs small maps that are multiples of 8 x 16");
+  }
   EAE_HIP(eae_smem_attr(reinterpret_cast<const void*>(kern), smem));
   if (hook) hook->begin(hook->user, st);
   hipLaunchKernelGGL(kern, dim3(slices * nblk), dim3(WG_THREADS), smem, st, a);

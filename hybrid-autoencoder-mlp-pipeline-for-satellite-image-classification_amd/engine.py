@@ -49,8 +49,9 @@ def _require_gpu(device):
 class AEEngine:
     """Owns the arenas + C context of one SupervisedAutoencoder (or a stand-alone Encoder / Decoder)."""
 
-    def __init__(self, root, max_batch=512):
+    def __init__(self, root, max_batch=512, quant=None):
         from .modules import SupervisedAutoencoder, Encoder, Decoder
+        self.quant = {None: 0, "bf16": 0, "fp8": 1, 0: 0, 1: 1}[quant]
         self.lib = _lib.load()
         self.root_ref = weakref.ref(root)
         if isinstance(root, SupervisedAutoencoder):
@@ -66,7 +67,7 @@ class AEEngine:
         p0 = next(root.parameters())
         self.device = p0.device
         _require_gpu(self.device)
-        self.cfg = EaeConfig(latent, classes, size, size, int(max_batch))
+        self.cfg = EaeConfig(latent, classes, size, size, int(max_batch), self.quant)
         self.max_batch = int(max_batch)
         poff = (C.c_longlong * 39)()
         boff = (C.c_longlong * 15)()
@@ -268,6 +269,19 @@ class AEEngine:
         return x_hat
 
     @_on_device
+    def fp8_calibrate(self, x, labels, alpha, head=True, iters=7):
+        """fp8 variant: settle the delayed scales on one batch before the first real step (include/eae.h, eae_fp8_calibrate)."""
+        io, keep = self._io(x, labels, True, head, alpha, None)
+        check(self.lib.eae_fp8_calibrate(self.ctx, _stream(), C.byref(io), int(iters)))
+
+    def fp8_scales(self):
+        """dict of the current per-tensor scales of the fp8 variant: 'act', 'grad', 'w' -> 6 floats (conv2..conv4, deconv1..deconv3)."""
+        out = (C.c_float * 18)()
+        check(self.lib.eae_fp8_scales(self.ctx, out))
+        v = list(out)
+        return {"act": v[0:6], "grad": v[6:12], "w": v[12:18]}
+
+    @_on_device
     def reset_optimizer(self):
         self.adam_m.zero_()
         self.adam_v.zero_()
@@ -311,10 +325,13 @@ def _root_of(module):
     return module
 
 
-def engine_for(module, max_batch=None):
-    """Engine of the SupervisedAutoencoder that owns `module` (or of a stand-alone Encoder / Decoder)."""
+def engine_for(module, max_batch=None, quant=None):
+    """Engine of the SupervisedAutoencoder that owns `module` (or of a stand-alone Encoder / Decoder).  quant="fp8": BASELINE config
+    5's variant (fp8 operands for the GEMMs of the six 3x3 layers, include/eae.h); it is a property of the engine, chosen when the
+    engine of a module is first built (`module._eae_quant = "fp8"` before the first use does the same)."""
     root = _root_of(module)
     eng = _ENGINES.get(root)
+    quant = quant if quant is not None else getattr(root, "_eae_quant", None)
     dev = next(root.parameters()).device
     _require_gpu(dev)
     want_mb = max_batch or getattr(root, "_eae_max_batch", 512)
@@ -324,7 +341,7 @@ def engine_for(module, max_batch=None):
     elif eng is not None and eng.max_batch < want_mb:
         old, eng = eng, None     # same parameters, bigger workspace: the optimizer state moves to the new engine
     if eng is None:
-        eng = AEEngine(root, max_batch=want_mb)
+        eng = AEEngine(root, max_batch=want_mb, quant=quant if old is None else old.quant)
         if old is not None:
             with torch.no_grad():
                 eng.adam_m.copy_(old.adam_m)

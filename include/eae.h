@@ -38,7 +38,19 @@ typedef struct eae_config {
   int image_h;       /* 64 for EuroSAT; must be a multiple of 64 */
   int image_w;
   int max_batch;     /* workspaces are sized for this many images per call */
+  int quant;         /* 0: bf16 operands.  1: BASELINE config 5's stress variant -- the GEMMs of the six 3x3 layers (forward,
+                        backward-data, weight gradient) take fp8 operands on v_mfma_f32_16x16x32_{fp8,bf8}_{fp8,bf8}: weights and
+                        activations OCP e4m3, gradients e5m2, per-tensor power-of-two scales with delayed scaling (eae_fp8_calibrate),
+                        fp32 accumulation, everything else as with 0.  Needs image_h % 128 == 0 and image_w % 256 == 0. */
 } eae_config;
+
+/* fp8 variant only.  eae_fp8_calibrate: `iters` (<= 0: 7) gradient steps WITHOUT optimizer on the given batch to settle the delayed
+ * scales before the first real step (running statistics are restored, the gradient arena is overwritten).
+ * eae_fp8_scales: the current scales, s_act[6], s_grad[6], s_w[6] for conv2, conv3, conv4, deconv1, deconv2, deconv3 (synchronises);
+ * a scale multiplies a value before its conversion. */
+struct eae_step_io;
+int eae_fp8_calibrate(eae_ctx* ctx, void* stream, const struct eae_step_io* io, int iters);
+int eae_fp8_scales(eae_ctx* ctx, float* out18);
 
 #define EAE_AE_NPARAMS 38   /* model.parameters() order of SupervisedAutoencoder */
 #define EAE_AE_NBN 7        /* BatchNorm2d layers: enc.encoder.{1,4,7,10}, dec.decoder.{2,5,8} */
@@ -161,6 +173,15 @@ typedef struct eae_src {
  * 1: ReLU mask of (yprev, prev_coef) + BN-backward partials; 2: plain store. */
 int eae_op_conv_s2(void* stream, int kind, eae_src src, int cin, int cout, int B, int Hin, int Win, const void* wpack,
                    const float* bias, void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef);
+/* fp8 variants of the two ops above (eae_config::quant = 1 uses them; maps must be multiples of 8 x 16 positions).
+ * conv: wpack_e4m3 = OCP e4m3 bytes [cout][9][cin] of w * s_w; qs (device) = {1/s_pixel, 1/(s_pixel*s_w)}; the pixel operand is
+ * converted to e4m3 (activation sources) or e5m2 (source mode 2, a gradient) in registers; amax (device, may be NULL) receives the
+ * largest |staged pixel operand| as float bits.  wgrad: qs (device) = {1/s_small, 1/s_big, 1/(s_small*s_big)}. */
+int eae_op_conv_s2_fp8(void* stream, int kind, eae_src src, int cin, int cout, int B, int Hin, int Win, const void* wpack_e4m3,
+                       const float* bias, void* out, float* stat_part, int epilogue, const void* yprev, const float* prev_coef,
+                       const float* qs, unsigned* amax);
+int eae_op_wgrad_s2_fp8(void* stream, eae_src small_src, eae_src big_src, int cs, int cb, int B, int Hs, int Ws, float* scratch,
+                        long long scratch_floats, float* dw, const float* qs);
 /* number of statistics partials per channel (= workgroups) eae_op_conv_s2 writes for this shape */
 int eae_op_conv_s2_ntiles(int kind, int cin, int B, int Hin, int Win);
 /* first / last layer kernels: src3_kind 0 = fp32 NCHW [B,3,H,W], 1 = bf16 NHWC4 [B,H,W,4]; out [B,H/2,W/2,32] */

@@ -47,7 +47,43 @@ def bf16_round(a):
 
 
 def _q(a, quant):
-    return bf16_round(a) if quant == "bf16" else a
+    return bf16_round(a) if quant in ("bf16", "fp8") else a
+
+
+def fp8_round(a, fmt):
+    """Round to OCP fp8 (round-to-nearest-even, saturating, with subnormals) and return as fp32.  fmt = "e4m3" (max 448, 3
+    mantissa bits, min normal 2^-6) or "e5m2" (max 57344, 2 mantissa bits, min normal 2^-14): what v_cvt_scalef32_pk_{fp8,bf8}_bf16
+    produces on gfx950 with MODE.FP16_OVFL set (tools/probe/probe_fp8.hip)."""
+    mant, emin, maxv = (3, -6, 448.0) if fmt == "e4m3" else (2, -14, 57344.0)
+    a = np.asarray(a, np.float32)
+    m = np.minimum(np.abs(a).astype(np.float64), maxv)
+    e = np.maximum(np.floor(np.log2(np.maximum(m, 1e-300))), emin)
+    q = np.exp2(e - mant)
+    r = np.minimum(np.round(m / q) * q, maxv)          # np.round: half to even
+    return (np.sign(a) * r).astype(np.float32)
+
+
+def fp8_bytes_e4m3(a):
+    """OCP e4m3 byte encoding of values that are already exactly representable (the output of fp8_round(., "e4m3"))."""
+    a = np.asarray(a, np.float32)
+    m = np.abs(a).astype(np.float64)
+    sign = (np.signbit(a)).astype(np.uint8) << 7
+    e = np.floor(np.log2(np.maximum(m, 2.0 ** -20)))
+    normal = m >= 2.0 ** -6
+    eb = np.where(normal, e + 7, 0).astype(np.int64)
+    mant = np.where(normal, np.round((m / np.exp2(e) - 1.0) * 8), np.round(m * 512)).astype(np.int64)
+    return (sign | (eb.astype(np.uint8) << 3) | mant.astype(np.uint8)).astype(np.uint8)
+
+
+def _q8(a, scale, fmt):
+    """Operand of an fp8 GEMM: the (already bf16-rounded) value times its power-of-two scale, rounded to fp8, divided back."""
+    sc = np.float32(scale)
+    return fp8_round(a * sc, fmt) / sc
+
+
+# 3x3 layers whose GEMMs take fp8 operands in the fp8 variant, in the engine's order (include/eae.h: eae_fp8_scales)
+FP8_ENC = {1: 0, 2: 1, 3: 2}      # ENC_CONVS index -> scale slot (conv2, conv3, conv4)
+FP8_DEC = {0: 3, 1: 4, 2: 5}      # DEC_DECONVS index -> scale slot (deconv1, deconv2, deconv3)
 
 
 # --------------------------------------------------------------------------------------
@@ -196,7 +232,7 @@ def mse(x_hat, x):
 # --------------------------------------------------------------------------------------
 # SupervisedAutoencoder (R.md:416-433): forward, loss, backward
 # --------------------------------------------------------------------------------------
-def ae_forward(p, x, train, quant=None, head=True):
+def ae_forward(p, x, train, quant=None, head=True, scales=None):
     """Forward of SupervisedAutoencoder.forward (R.md:429-433) -> dict with x_hat, logits, z.
 
     ``p`` maps reference state-dict names to fp32 arrays.  Returns also ``cache`` for backward and
@@ -208,7 +244,11 @@ def ae_forward(p, x, train, quant=None, head=True):
     # ---- Encoder R.md:291-310
     for li, (ci_, bi_) in enumerate(ENC_CONVS):
         w = _q(p[f"enc.encoder.{ci_}.weight"], quant)
-        y = conv_s2_fwd(a, w, p[f"enc.encoder.{ci_}.bias"])
+        if quant == "fp8" and li in FP8_ENC:      # quant="fp8": `scales` = {"act": [6], "grad": [6], "w": [6]} (the engine's, delayed)
+            j = FP8_ENC[li]
+            y = conv_s2_fwd(_q8(a, scales["act"][j], "e4m3"), _q8(w, scales["w"][j], "e4m3"), p[f"enc.encoder.{ci_}.bias"])
+        else:
+            y = conv_s2_fwd(a, w, p[f"enc.encoder.{ci_}.bias"])
         y = _q(y, quant)                        # raw conv output is stored bf16 on the HIP path
         o, bc, rm, rv = bn_fwd(y, p[f"enc.encoder.{bi_}.weight"], p[f"enc.encoder.{bi_}.bias"],
                                p[f"enc.encoder.{bi_}.running_mean"], p[f"enc.encoder.{bi_}.running_var"],
@@ -230,7 +270,11 @@ def ae_forward(p, x, train, quant=None, head=True):
     a = d.reshape(n, 256, x.shape[2] // 16, x.shape[3] // 16)    # nn.Unflatten(1,(256,4,4))
     for li, (di_, bi_) in enumerate(DEC_DECONVS):
         w = _q(p[f"dec.decoder.{di_}.weight"], quant)
-        y = deconv_s2_fwd(a, w, p[f"dec.decoder.{di_}.bias"])
+        if quant == "fp8" and li in FP8_DEC:
+            j = FP8_DEC[li]
+            y = deconv_s2_fwd(_q8(a, scales["act"][j], "e4m3"), _q8(w, scales["w"][j], "e4m3"), p[f"dec.decoder.{di_}.bias"])
+        else:
+            y = deconv_s2_fwd(a, w, p[f"dec.decoder.{di_}.bias"])
         if bi_ is None:
             x_hat = sigmoid(y)                  # nn.Sigmoid R.md:383
             cache[f"dec{li}"] = (a, y, None, None)
@@ -266,7 +310,15 @@ def ae_loss(out, x, labels, alpha, head=True):
     return np.float32(alpha * l_r + l_c), l_r, l_c
 
 
-def ae_backward(p, out, x, labels, alpha, quant=None, head=True, dout=None):
+def _bwd8(fn, a, w, dy, j, scales):
+    """Backward of one 3x3 layer with fp8 GEMM operands: backward-data from (w e4m3, dy e5m2), weight gradient from (a e4m3, dy e5m2)."""
+    dy8 = _q8(dy, scales["grad"][j], "e5m2")
+    da, _, db = fn(a, _q8(w, scales["w"][j], "e4m3"), dy8)
+    _, dw, _ = fn(_q8(a, scales["act"][j], "e4m3"), w, dy8)
+    return da, dw, db
+
+
+def ae_backward(p, out, x, labels, alpha, quant=None, head=True, dout=None, scales=None):
     """Gradients of alpha*MSE + CE w.r.t. all 38 parameters (autograd of R.md:653) + dz.
 
     ``dout`` = optional externally supplied (dx_hat, dlogits, dz) replacing the fused loss.
@@ -304,7 +356,10 @@ def ae_backward(p, out, x, labels, alpha, quant=None, head=True, dout=None):
         dy, dgam, dbet = bn_bwd(gm, p[f"dec.decoder.{bi_}.weight"], bc, (0, 2, 3))
         g[f"dec.decoder.{bi_}.weight"], g[f"dec.decoder.{bi_}.bias"] = dgam, dbet
         dy = _q(dy, quant)
-        da, dw, db = deconv_s2_bwd(a, _q(p[f"dec.decoder.{di_}.weight"], quant), dy)
+        if quant == "fp8":
+            da, dw, db = _bwd8(deconv_s2_bwd, a, _q(p[f"dec.decoder.{di_}.weight"], quant), dy, FP8_DEC[li], scales)
+        else:
+            da, dw, db = deconv_s2_bwd(a, _q(p[f"dec.decoder.{di_}.weight"], quant), dy)
         g[f"dec.decoder.{di_}.weight"], g[f"dec.decoder.{di_}.bias"] = dw, db
     dd = _q(da.reshape(n, -1), quant)
     dzd, g["dec.decoder_input.weight"], g["dec.decoder_input.bias"] = linear_bwd(
@@ -322,7 +377,10 @@ def ae_backward(p, out, x, labels, alpha, quant=None, head=True, dout=None):
         dy, dgam, dbet = bn_bwd(gm, p[f"enc.encoder.{bi_}.weight"], bc, (0, 2, 3))
         g[f"enc.encoder.{bi_}.weight"], g[f"enc.encoder.{bi_}.bias"] = dgam, dbet
         dy = _q(dy, quant)
-        da, dw, db = conv_s2_bwd(a, _q(p[f"enc.encoder.{ci_}.weight"], quant), dy)
+        if quant == "fp8" and li in FP8_ENC:
+            da, dw, db = _bwd8(conv_s2_bwd, a, _q(p[f"enc.encoder.{ci_}.weight"], quant), dy, FP8_ENC[li], scales)
+        else:
+            da, dw, db = conv_s2_bwd(a, _q(p[f"enc.encoder.{ci_}.weight"], quant), dy)
         g[f"enc.encoder.{ci_}.weight"], g[f"enc.encoder.{ci_}.bias"] = dw, db
     g["dx"] = da
     return g

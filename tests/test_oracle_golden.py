@@ -121,6 +121,25 @@ def test_ae_eval_b1_and_latent128(golden):
     assert abs(l_c - g["ce"]) < 1e-5 and abs(l_r - g["mse"]) < 1e-6
 
 
+def test_fp8_rounding_matches_the_hardware_probe():
+    """oracle.fp8_round against what v_cvt_scalef32_pk_fp8_bf16 produced on an MI355X (tools/probe/probe_fp8.hip, MODE.FP16_OVFL
+    set): OCP e4m3 bytes 1 -> 0x38, 0.5 -> 0x30, -3 -> 0xc4, 448 -> 0x7e, 1000 -> 0x7e (saturates), 2^-9 -> 0x01, 2^-10 -> 0x00,
+    17 -> 0x58; with scale 2 (the instruction DIVIDES by its scale operand) 1 -> 0x30, 448 -> 0x76; with scale 0.5 2^-10 -> 0x01."""
+    def decode_e4m3(b):
+        s = -1.0 if b & 0x80 else 1.0
+        e, m = (b >> 3) & 0xf, b & 7
+        return s * (m * 2.0 ** -9 if e == 0 else (1 + m / 8.0) * 2.0 ** (e - 7))
+    v = np.array([1.0, 0.5, -3.0, 448.0, 1000.0, 2.0 ** -9, 2.0 ** -10, 17.0], np.float32)
+    hw = {1.0: [0x38, 0x30, 0xc4, 0x7e, 0x7e, 0x01, 0x00, 0x58], 2.0: [0x30, 0x28, 0xbc, 0x76, 0x7e, 0x00, 0x00, 0x50],
+          0.5: [0x40, 0x38, 0xcc, 0x7e, 0x7e, 0x02, 0x01, 0x60]}
+    for scale, bytes_ in hw.items():
+        want = np.array([decode_e4m3(b) for b in bytes_], np.float32)
+        assert np.array_equal(O.fp8_round(v / np.float32(scale), "e4m3"), want), scale
+    # e5m2: 2 mantissa bits, max 57344, subnormal step 2^-16; ties to even
+    assert np.array_equal(O.fp8_round(np.array([1.0, 1.125, 1.375, 7e4, 2.0 ** -16, 2.0 ** -17, 1000.0], np.float32), "e5m2"),
+                          np.array([1.0, 1.0, 1.5, 57344.0, 2.0 ** -16, 0.0, 1024.0], np.float32))
+
+
 def test_ae_latent48(golden):
     """A latent width that is not a multiple of 64 (ae_latent48_b8.npz, reference run): forward, loss and every gradient."""
     g = golden("ae_latent48_b8.npz")
