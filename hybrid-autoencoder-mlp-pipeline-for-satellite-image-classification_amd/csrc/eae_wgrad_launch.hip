@@ -15,17 +15,19 @@ int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_fl
   // kernels run beside the backward-data chain, and what counts is how many CUs they take from it: 64 workgroups measured best for
   // every layer (ms per step at B=512 / B=64: 32: 0.599 / 0.241, 48: 0.540, 64: 0.500-0.512 / 0.244, 80: 0.515, 128: 0.509-0.527 /
   // 0.271, 256: 0.542).  EAE_WGRAD_WGS=<n> or <n one-block layers>,<n wider layers> overrides.
-  static int wgs_one = 64, wgs_wide = 64;
+  static int wgs_one = 64, wgs_wide = 64, wgs_last = 64;
   static const bool parsed = [] {
     if (const char* e = getenv("EAE_WGRAD_WGS")) {
-      int a = 0, b = 0;
-      const int n = sscanf(e, "%d,%d", &a, &b);
-      if (n >= 1 && a > 0) { wgs_one = a; wgs_wide = (n == 2 && b > 0) ? b : a; }
+      int a = 0, b = 0, c = 0;
+      const int n = sscanf(e, "%d,%d,%d", &a, &b, &c);
+      if (n >= 1 && a > 0) { wgs_one = a; wgs_wide = (n >= 2 && b > 0) ? b : a; wgs_last = (n >= 3 && c > 0) ? c : wgs_one; }
     }
     return true;
   }();
   (void)parsed;
-  const int wgs = nblk == 1 ? wgs_one : wgs_wide;
+  // enc.conv2's weight gradient is the last one of the step: it runs in the tail, beside conv2's backward-data and conv1's weight gradient only
+  constexpr bool LAST = (CS == 64 && SM == SRC_BNBWD);
+  const int wgs = LAST ? wgs_last : (nblk == 1 ? wgs_one : wgs_wide);
   int slices = wgs / nblk;
   if (slices < 1) slices = 1;
   if (slices > ntiles) slices = ntiles;
