@@ -27,3 +27,17 @@ torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"B={B}: host enqueue {1e6 * (t1 - t0) / N:.1f} us/step, wall {1e6 * (t2 - t0) / N:.1f} us/step "
       f"(queue drained {1e3 * (t2 - t1):.2f} ms after the last enqueue)")
+
+# the same step through the C entry point alone (argument struct built once): what the Python wrapper costs on top
+import ctypes as C  # noqa: E402
+io, keep = eng._io(x, y, True, True, 35.0, None)
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+lr = C.c_float(1e-3)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(N):
+    eng.lib.eae_ae_train_step(eng.ctx, st, C.byref(io), lr)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"B={B}: C call alone: host enqueue {1e6 * (t1 - t0) / N:.1f} us/step, wall {1e6 * (t2 - t0) / N:.1f} us/step")
