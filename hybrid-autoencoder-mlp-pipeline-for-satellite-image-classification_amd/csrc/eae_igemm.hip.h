@@ -195,7 +195,14 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& a, bf16_t* tile, f
                                               RowMap rowmap) {
   TileEpilogue<COUT, BN, EPI> e;
   e.begin(a, n0);
-  e.rows(a, tile, n0, nrows, rowmap);
+  if constexpr (EPI == EPI_MASK) {      // (every caller has 128-row tiles) all rows of the previous layer's tensor requested at once
+    constexpr int RPP = 256 / (BN / 8), NIT = (128 + RPP - 1) / RPP;
+    uint4 yv[NIT];
+    e.template load_prev<NIT>(a, n0, nrows, rowmap, yv);
+    e.template rows_pre<NIT>(a, tile, n0, nrows, rowmap, yv);
+  } else {
+    e.rows(a, tile, n0, nrows, rowmap);
+  }
   e.end(a, red, n0, tile_id);
 }
 
