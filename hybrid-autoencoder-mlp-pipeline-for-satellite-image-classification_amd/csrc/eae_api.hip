@@ -46,7 +46,7 @@ int check_cfg(const eae_config* c) {
   if (!c) return eae_set_error(EAE_ERR_ARG, "config is NULL");
   if (c->image_h <= 0 || c->image_w <= 0 || c->image_h % 64 || c->image_w % 64) return eae_set_error(EAE_ERR_ARG, "image size must be a positive multiple of 64");
   if (c->latent_dim <= 0 || c->latent_dim > 256) return eae_set_error(EAE_ERR_ARG, "latent_dim must be in 1..256");
-  if (c->num_classes <= 0 || c->num_classes > 16) return eae_set_error(EAE_ERR_ARG, "num_classes must be in 1..16");
+  if (c->num_classes <= 0 || c->num_classes > 64) return eae_set_error(EAE_ERR_ARG, "num_classes must be in 1..64");
   if (c->max_batch <= 0) return eae_set_error(EAE_ERR_ARG, "max_batch must be positive");
   if (c->quant != 0 && c->quant != 1) return eae_set_error(EAE_ERR_ARG, "quant must be 0 (bf16) or 1 (fp8 conv GEMMs)");
   if (c->quant == 1 && (c->image_h % 128 || c->image_w % 256))

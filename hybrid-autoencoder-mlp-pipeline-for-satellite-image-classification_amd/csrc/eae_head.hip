@@ -7,6 +7,7 @@
 #include "eae_head.h"
 
 constexpr int HR = 8;   // batch rows per block
+constexpr int HC = 64;  // logits row stride in LDS = largest class count
 
 __global__ EAE_NO_PK __launch_bounds__(256) void head_kernel(HeadArgs a) {
   extern __shared__ float sm[];
@@ -16,10 +17,10 @@ __global__ EAE_NO_PK __launch_bounds__(256) void head_kernel(HeadArgs a) {
   float* w2 = zt + HR * L;           // [C][128]
   float* hp = w2 + C * 128;          // [32][129]  pre-activation
   float* dh = hp + HR * 129;         // [HR][129]
-  float* lg = dh + HR * 129;         // [32][16]   logits, then dlogits
-  float* b1 = lg + HR * 16;          // [128]
-  float* b2 = b1 + 128;              // [16]
-  float* rl = b2 + 16;               // [HR] per-row loss, [HR] per-row correct
+  float* lg = dh + HR * 129;         // [HR][HC]   logits, then dlogits
+  float* b1 = lg + HR * HC;          // [128]
+  float* b2 = b1 + 128;              // [HC]
+  float* rl = b2 + HC;               // [HR] per-row loss, [HR] per-row correct
   const int tid = threadIdx.x;
   const int r0 = blockIdx.x * HR;
   for (int i = tid; i < 128 * L; i += 256) w1[(i / L) * LS + (i % L)] = a.w1[i];
@@ -50,33 +51,33 @@ __global__ EAE_NO_PK __launch_bounds__(256) void head_kernel(HeadArgs a) {
     int r = i / C, c = i % C;
     float s = b2[c];
     for (int j = 0; j < 128; ++j) s = fmaf(fmaxf(hp[r * 129 + j], 0.f), w2[c * 128 + j], s);
-    lg[r * 16 + c] = s;
+    lg[r * HC + c] = s;
   }
   __syncthreads();
   if (tid < HR) {   // softmax + CE per row
     int r = r0 + tid;
     float loss = 0.f, correct = 0.f;
     if (r < a.B) {
-      float mx = lg[tid * 16];
+      float mx = lg[tid * HC];
       int am = 0;
-      for (int c = 1; c < C; ++c) if (lg[tid * 16 + c] > mx) { mx = lg[tid * 16 + c]; am = c; }
+      for (int c = 1; c < C; ++c) if (lg[tid * HC + c] > mx) { mx = lg[tid * HC + c]; am = c; }
       float se = 0.f;
-      for (int c = 0; c < C; ++c) se += expf(lg[tid * 16 + c] - mx);
+      for (int c = 0; c < C; ++c) se += expf(lg[tid * HC + c] - mx);
       float lse = logf(se) + mx;
-      if (a.logits) for (int c = 0; c < C; ++c) a.logits[(size_t)r * C + c] = lg[tid * 16 + c];
+      if (a.logits) for (int c = 0; c < C; ++c) a.logits[(size_t)r * C + c] = lg[tid * HC + c];
       if (a.dlogits_in) {
-        for (int c = 0; c < C; ++c) lg[tid * 16 + c] = a.dlogits_in[(size_t)r * C + c];
+        for (int c = 0; c < C; ++c) lg[tid * HC + c] = a.dlogits_in[(size_t)r * C + c];
       } else if (a.labels) {
         int lab = (int)a.labels[r];
-        loss = lse - lg[tid * 16 + lab];
+        loss = lse - lg[tid * HC + lab];
         correct = (am == lab) ? 1.f : 0.f;
         for (int c = 0; c < C; ++c) {
-          float pr = expf(lg[tid * 16 + c] - lse);
-          lg[tid * 16 + c] = (pr - (c == lab ? 1.f : 0.f)) * a.inv_batch;
+          float pr = expf(lg[tid * HC + c] - lse);
+          lg[tid * HC + c] = (pr - (c == lab ? 1.f : 0.f)) * a.inv_batch;
         }
       }
     } else {
-      for (int c = 0; c < C; ++c) lg[tid * 16 + c] = 0.f;
+      for (int c = 0; c < C; ++c) lg[tid * HC + c] = 0.f;
     }
     rl[tid] = loss; rl[HR + tid] = correct;
   }
@@ -91,7 +92,7 @@ __global__ EAE_NO_PK __launch_bounds__(256) void head_kernel(HeadArgs a) {
     const int j = tid & 127, rh = tid >> 7;
     for (int r = rh * (HR / 2); r < (rh + 1) * (HR / 2); ++r) {
       float s = 0.f;
-      for (int c = 0; c < C; ++c) s = fmaf(lg[r * 16 + c], w2[c * 128 + j], s);
+      for (int c = 0; c < C; ++c) s = fmaf(lg[r * HC + c], w2[c * 128 + j], s);
       dh[r * 129 + j] = hp[r * 129 + j] > 0.f ? s : 0.f;
     }
   }
@@ -119,19 +120,19 @@ __global__ EAE_NO_PK __launch_bounds__(256) void head_kernel(HeadArgs a) {
   for (int i = tid; i < C * 128; i += 256) {
     int c = i / 128, j = i % 128;
     float s = 0.f;
-    for (int r = 0; r < HR; ++r) s = fmaf(lg[r * 16 + c], fmaxf(hp[r * 129 + j], 0.f), s);
+    for (int r = 0; r < HR; ++r) s = fmaf(lg[r * HC + c], fmaxf(hp[r * 129 + j], 0.f), s);
     gp[128 * L + 128 + i] = s;
   }
   if (tid < ((C + 3) & ~3)) {
     float s = 0.f;
-    if (tid < C) for (int r = 0; r < HR; ++r) s += lg[r * 16 + tid];
+    if (tid < C) for (int r = 0; r < HR; ++r) s += lg[r * HC + tid];
     gp[128 * L + 128 + C * 128 + tid] = s;
   }
 }
 
 int eae_launch_head(hipStream_t st, const HeadArgs& a) {
-  if (a.L > 256 || a.C > 16 || a.L % 4) return eae_set_error(-2, "head: latent_dim must be <= 256 (multiple of 4), classes <= 16");
-  size_t smem = sizeof(float) * ((size_t)128 * (a.L + 1) + HR * a.L + a.C * 128 + 2 * HR * 129 + HR * 16 + 128 + 16 + 2 * HR);
+  if (a.L > 256 || a.C > HC || a.L % 4) return eae_set_error(-2, "head: latent_dim must be <= 256 (multiple of 4), classes <= 64");
+  size_t smem = sizeof(float) * ((size_t)128 * (a.L + 1) + HR * a.L + a.C * 128 + 2 * HR * 129 + HR * HC + 128 + HC + 2 * HR);
   static size_t attr = 0;
   if (smem > attr) {
     EAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -581,7 +581,9 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
         *reinterpret_cast<uint2*>(tile + (row * PHG + px) * TS + wn * 16 + kgl * 4) = w2;
       }
     }
+    EAE_STAMP(40 + pass * 4 + 0);
     __syncthreads();
+    EAE_STAMP(40 + pass * 4 + 1);
     if (do_stats) {
 #pragma unroll
       for (int ks = 0; ks < R2 / 32; ++ks) {
@@ -591,12 +593,14 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
         st2 = mfma16(fr, fr, st2);
       }
     }
+    EAE_STAMP(40 + pass * 4 + 2);
     if constexpr (EPI == EPI_MASK) {
       if (pass + 1 < NPH / PHG) epi.template load_prev<NIT>(a, n0, R2, rowmap_of(pass + 1), yv[(pass + 1) & 1]);
       epi.template rows_pre<NIT>(a, tile, n0, R2, rowmap_of(pass), yv[pass & 1]);
     } else {
       epi.rows(a, tile, n0, R2, rowmap_of(pass));
     }
+    EAE_STAMP(40 + pass * 4 + 3);
   }
   EAE_STAMP(6);
   if (do_stats) {

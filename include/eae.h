@@ -34,7 +34,7 @@ typedef struct eae_ctx eae_ctx;
 typedef struct eae_config {
   int latent_dim;    /* Encoder/Decoder/SupervisedAutoencoder(latent_dim)  R.md:288, 362, 417; any width in 1..256 (padded to a
                         multiple of 64 inside the packs and workspaces; the parameter / gradient arenas keep the reference shapes) */
-  int num_classes;   /* SupervisedAutoencoder(num_classes=10)             R.md:417 */
+  int num_classes;   /* SupervisedAutoencoder(num_classes=10)             R.md:417; 1..64 */
   int image_h;       /* 64 for EuroSAT; must be a multiple of 64 */
   int image_w;
   int max_batch;     /* workspaces are sized for this many images per call */

@@ -246,6 +246,38 @@ def test_latent_width_not_a_multiple_of_64_vs_golden(golden, latent):
         assert err.max() <= 2 * lr + 1e-4 and (s.size < 50 or float(np.mean(err < 1e-4)) >= 0.90), (name, float(err.max()))
 
 
+def test_num_classes_other_than_10_vs_oracle():
+    """The reference takes any num_classes (R.md:417, 426); the head kernel holds up to 64.  37 classes, latent 48, B=8 against the
+    oracle (the head is fp32 end to end: logits and the classifier gradients are tight)."""
+    import eae_amd
+    import gpu_util as G
+    torch.manual_seed(11)
+    m = eae_amd.SupervisedAutoencoder(latent_dim=48, num_classes=37)
+    p = gu.perturb_bn({k: v.detach().numpy().copy() for k, v in m.state_dict().items()})
+    load_state_np(m, p)
+    m = m.to("cuda")
+    x, _ = gu.make_images(8, 321)
+    y = np.random.default_rng(5).integers(0, 37, 8).astype(np.int64)
+    eng = _engine(m, max_batch=8)
+    xh, lg, z = eng.forward(_cuda(x), labels=_cuda(y), train=True, alpha=35.0)
+    eng.grad_step(_cuda(x), _cuda(y), 35.0)
+    torch.cuda.synchronize()
+    eng.expose_grads()
+    out = O.ae_forward(p, x, train=True, quant="bf16")
+    assert tuple(lg.shape) == (8, 37)
+    assert np.abs(lg.cpu().numpy() - out["logits"]).max() <= 0.02 * np.abs(out["logits"]).max()
+    loss, l_r, l_c = O.ae_loss(out, x, y, 35.0)
+    got = eng.loss_last.cpu().numpy()
+    assert abs(got[2] - l_c) <= 2e-2 * abs(l_c) and abs(got[1] - l_r) <= 2e-2 * l_r, (got, l_r, l_c)
+    gq = O.ae_backward(p, out, x, y, 35.0, quant="bf16")
+    for name in ("classifier.0.weight", "classifier.0.bias", "classifier.2.weight", "classifier.2.bias", "enc.encoder.13.weight"):
+        got_g = dict(m.named_parameters())[name].grad.cpu().numpy()
+        assert got_g.shape == gq[name].shape
+        assert G.cosine(got_g, gq[name]) > 0.995, (name, G.cosine(got_g, gq[name]))
+    with pytest.raises(Exception, match="num_classes"):
+        _engine(eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=65).cuda(), max_batch=4)
+
+
 @pytest.mark.parametrize("tag,head", [("joint", True), ("recon", False)])
 def test_adam_trajectory_vs_golden(golden, tag, head):
     g = golden(f"ae_adam5_{tag}_b8.npz")

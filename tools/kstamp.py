@@ -46,4 +46,10 @@ for (kind, ci, co, hin, smode, epi) in CASES:
             nxt = t[8 + (c + 1) * 4] if c + 1 < nc else t[4]
             msg.append(f"c{c}: stage {t[b+1]-t[b]} bar {t[b+2]-t[b+1]} issue {t[b+3]-t[b+2]} mfma(+bar) {nxt-t[b+3]}")
         msg.append(f"epilogue: barrier {t[5]-t[4]} tile+rows {t[6]-t[5]} stats {t[7]-t[6]}")
+        np_ = 2 if kind == 1 else 1
+        prev = t[5]
+        for ps in range(np_):
+            b = 40 + ps * 4
+            msg.append(f"pass{ps}: tilewrite {t[b]-prev} barrier {t[b+1]-t[b]} mfma-stats {t[b+2]-t[b+1]} rows {t[b+3]-t[b+2]}")
+            prev = t[b + 3]
         print(" | ".join(msg))
