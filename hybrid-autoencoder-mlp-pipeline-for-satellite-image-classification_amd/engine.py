@@ -332,6 +332,9 @@ def engine_for(module, max_batch=None, quant=None):
     root = _root_of(module)
     eng = _ENGINES.get(root)
     quant = quant if quant is not None else getattr(root, "_eae_quant", None)
+    if eng is not None and quant is not None and eng.quant != {"bf16": 0, "fp8": 1, 0: 0, 1: 1}[quant]:
+        raise RuntimeError("this module already has an engine with a different `quant`; the operand format is fixed when the engine is "
+                           "first built (set module._eae_quant before the first forward, or pass quant= to the first engine_for call)")
     dev = next(root.parameters()).device
     _require_gpu(dev)
     want_mb = max_batch or getattr(root, "_eae_max_batch", 512)
