@@ -281,6 +281,48 @@ __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc*
     if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&q->amax_w[d.q_layer], __float_as_uint(mx));
     return;
   }
+  if ((d.mode == PACK_3x3_P1 || d.mode == PACK_3x3_P2) && !d.out_f32) {
+    // 3x3 weights W[a][b][3][3]: one thread per (a, b) reads its 9 consecutive floats and writes them one tap-row apart; the lanes of
+    // a wave run over b for P1 = [a][9][b] and over a for P2 = [b][9][a], so every store instruction of a wave is contiguous and
+    // every source line is read once (the element-per-thread mapping gathered one float per line and lane for P2)
+    const unsigned A = (unsigned)d.d0, Bq = (unsigned)d.d1;
+    const bool p1 = d.mode == PACK_3x3_P1;
+    bf16_t* dst = reinterpret_cast<bf16_t*>(pack_base + d.dst_off);
+    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < A * Bq; t += gridDim.x * 256u) {
+      const unsigned a = p1 ? t / Bq : t % A, b = p1 ? t % Bq : t / A;
+      const float* sp = src + ((size_t)a * Bq + b) * 9;
+      float w[9];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) w[tap] = sp[tap];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+        dst[p1 ? ((size_t)a * 9 + tap) * Bq + b : ((size_t)b * 9 + tap) * A + a] = (bf16_t)f2bf(w[tap]);
+    }
+    return;
+  }
+  if ((d.mode == PACK_FC_ROWMAJOR_KPERM || d.mode == PACK_FC_TRANS_KPERM) && (d.d2 & 3) == 0 && !d.out_f32) {
+    // enc.fc's two layouts (k' = p*Cc + c <- k = c*P + p).  One thread per (row r, channel c) reads its P consecutive source floats
+    // (whole cache lines, each read once) and writes them P rows apart; the lanes of a wave run over c (row-major form) or over r
+    // (transposed form), so every store instruction of a wave covers 128 contiguous bytes.  The element-per-thread mapping of
+    // pack_fetch reads one float per 64-byte line and lane: 16x the L2 traffic for these two packs.
+    const unsigned R = (unsigned)d.d0, Cc = (unsigned)d.d1, P = (unsigned)d.d2, K = Cc * P, lv = (unsigned)d.lv;
+    const bool rowmajor = d.mode == PACK_FC_ROWMAJOR_KPERM;
+    bf16_t* dst = reinterpret_cast<bf16_t*>(pack_base + d.dst_off);
+    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < R * Cc; t += gridDim.x * 256u) {
+      const unsigned r = rowmajor ? t / Cc : t % R, c = rowmajor ? t % Cc : t / R;
+      const float* sp = src + (size_t)r * K + (size_t)c * P;
+      for (unsigned p = 0; p < P; p += 4) {
+        const float4 v = r < lv ? *reinterpret_cast<const float4*>(sp + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (unsigned q = 0; q < 4; ++q) {
+          const size_t o = rowmajor ? (size_t)r * K + (size_t)(p + q) * Cc + c : ((size_t)(p + q) * Cc + c) * R + r;
+          dst[o] = (bf16_t)f2bf(e[q]);
+        }
+      }
+    }
+    return;
+  }
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
     float v = pack_fetch(d, src, i);
     if (d.out_f32) reinterpret_cast<float*>(pack_base + d.dst_off)[i] = v;
