@@ -78,6 +78,9 @@ struct eae_ctx {
   long long adam_step = 0;
   bool packed = false;
   bool fwd_ready = false;          // a train-mode forward with gradient staging is resident in the workspace
+  bool fwd_eval_ready = false;     // ... or an eval-mode one (BatchNorm with running statistics): eae_ae_backward differentiates that too
+  bool bwd_eval = false;           // the running backward differentiates an eval-mode forward: BatchNorm is a per-channel affine map
+  bool prebn_dirty = false;        // an eval-mode backward wrote the gradients of the biases in front of the BatchNorms (train mode: zero)
   int fwd_B = 0, fwd_head = 0;
   const float* fwd_x = nullptr;    // only used between eae_ae_grad_step_begin / _end (the caller keeps the batch alive in between)
   long long fwd_gen = 0;           // bumped by every forward: eae_ae_backward refuses to differentiate a forward that is no longer resident
@@ -426,7 +429,7 @@ extern "C" int eae_destroy(eae_ctx* c) {
 extern "C" int eae_bind(eae_ctx* c, float* params, float* grads, float* adam_m, float* adam_v, float* bn_running, long long* bn_nbt) {
   if (!c || !params || !bn_running) return eae_set_error(EAE_ERR_ARG, "bind: ctx, params and bn_running are required");
   c->P = params; c->G = grads; c->M = adam_m; c->V = adam_v; c->bnrun = bn_running; c->nbt = bn_nbt;
-  c->packed = false; c->fwd_ready = false;
+  c->packed = false; c->fwd_ready = false; c->fwd_eval_ready = false;
   if (grads)
     for (int k = 0; k < 7; ++k)
       EAE_HIP(hipMemset(grads + c->poff[PREBN_BIAS[k]], 0, (size_t)(c->poff[PREBN_BIAS[k] + 1] - c->poff[PREBN_BIAS[k]]) * 4));
@@ -459,7 +462,7 @@ extern "C" long long eae_gate_timeouts(eae_ctx* c) {
   if (hipMemcpy(&v, c->sigwords + 8, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (long long)v;
 }
-extern "C" int eae_params_changed(eae_ctx* c) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->packed = false; c->fwd_ready = false; return 0; }
+extern "C" int eae_params_changed(eae_ctx* c) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->packed = false; c->fwd_ready = false; c->fwd_eval_ready = false; return 0; }
 extern "C" int eae_set_adam_step(eae_ctx* c, long long s) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->adam_step = s; return 0; }
 extern "C" long long eae_get_adam_step(eae_ctx* c) { return c ? c->adam_step : -1; }
 
@@ -689,13 +692,18 @@ void fold_bwd_producer(eae_ctx* c, ConvArgs& a, int l) {
 void fold_bwd_consumer(eae_ctx* c, BnBwdFold& f, int l, long long count, bool writer) {
   f = BnBwdFold();
   if (!bwd_folded(c, l)) return;
-  f.acc = c->accb[l]; f.copies = bwd_copies(c, l); f.inv_scale = 1.0f / ACC_SCALE_BWD; f.count = (float)count;
+  f.acc = c->accb[l]; f.copies = bwd_copies(c, l); f.inv_scale = 1.0f / ACC_SCALE_BWD;
+  f.count = c->bwd_eval ? __builtin_inff() : (float)count;
   f.gamma = c->P + c->poff[BN_GAMMA_IDX[l]]; f.coef_fwd = c->coef_f[l];
-  if (writer) { f.dgamma = c->G + c->poff[BN_GAMMA_IDX[l]]; f.dbeta = c->G + c->poff[BN_GAMMA_IDX[l] + 1]; f.coef_out = c->coef_b[l]; }
+  if (writer) {
+    f.dgamma = c->G + c->poff[BN_GAMMA_IDX[l]]; f.dbeta = c->G + c->poff[BN_GAMMA_IDX[l] + 1]; f.coef_out = c->coef_b[l];
+    if (c->bwd_eval) f.dbias = c->G + c->poff[PREBN_BIAS[l]];
+  }
 }
 
 int bn_bwd_fin(eae_ctx* c, hipStream_t st, int l, int ntiles, long long count) {
   if (bwd_folded(c, l)) return 0;           // folded into the producer (accumulators) and its consumers (prologue)
+  if (c->bwd_eval) count = 1LL << 40;       // eval-mode BatchNorm: no batch-size terms (see eae_ae_backward)
   if (c->sync_world > 1) {
     double* sums = c->sync_sums + (size_t)l * 512;
     RC(eae_launch_bn_bwd_reduce(st, c->stat, ntiles, BN_C[l], sums, c->G + c->poff[BN_GAMMA_IDX[l]], c->G + c->poff[BN_GAMMA_IDX[l] + 1]));
@@ -836,7 +844,7 @@ int check_io(eae_ctx* c, const eae_step_io* io, bool need_grad) {
 int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_grad) {
   const int B = io->B;
   const bool train = io->train != 0;
-  c->fwd_ready = train; c->fwd_B = B; c->fwd_head = io->head; c->fwd_x = io->x; c->fwd_gen += 1;
+  c->fwd_ready = train; c->fwd_eval_ready = !train; c->fwd_B = B; c->fwd_head = io->head; c->fwd_x = io->x; c->fwd_gen += 1;
   RC(ensure_packed(c, st));
   RC(prep_accumulators(c, st, train));
   RC(run_encoder(c, st, io->x, B, train));
@@ -886,6 +894,11 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
 // part 0 = everything, 1 = classifier + decoder + dec.fc (gradient tensors 18..37), 2 = enc.fc + encoder (tensors 0..17)
 int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float* dz_ext = nullptr, int part = 0) {
   const int B = io->B, H = c->H, W = c->W;
+  if (c->prebn_dirty && !c->bwd_eval) {      // train mode again: those biases have an identically zero gradient, never written
+    for (int k = 0; k < 7; ++k)
+      EAE_HIP(hipMemsetAsync(c->G + c->poff[PREBN_BIAS[k]], 0, (size_t)(c->poff[PREBN_BIAS[k] + 1] - c->poff[PREBN_BIAS[k]]) * 4, st));
+    c->prebn_dirty = false;
+  }
   const bool head = io->head != 0;
   // Default: every weight gradient is handed over as soon as its inputs exist (9 records).  EAE_FORK_GROUPS=1 hands them over in
   // 5 groups instead: measured SLOWER (0.596 vs 0.570 ms at B=512) -- the records saved (~5 us each) cost less than what two
@@ -1101,7 +1114,7 @@ extern "C" long long eae_forward_generation(eae_ctx* c) { return c ? c->fwd_gen 
 extern "C" int eae_ae_backward(eae_ctx* c, void* stream, long long generation, const float* x, const float* x_hat, const float* dx_hat,
                                const float* dlogits, const float* dz) {
   if (!c || !c->G) return eae_set_error(EAE_ERR_STATE, "backward: no gradient arena bound");
-  if (!c->fwd_ready) return eae_set_error(EAE_ERR_STATE, "backward: no train-mode forward is resident (call eae_ae_forward with train=1 first)");
+  if (!c->fwd_ready && !c->fwd_eval_ready) return eae_set_error(EAE_ERR_STATE, "backward: no forward is resident (call eae_ae_forward first)");
   if (generation != c->fwd_gen)
     return eae_set_error(EAE_ERR_STATE, "backward: a later forward has replaced the activations of the forward being differentiated "
                                         "(one backward per forward, in order)");
@@ -1114,9 +1127,17 @@ extern "C" int eae_ae_backward(eae_ctx* c, void* stream, long long generation, c
   const int nblk = (int)(((long long)B * c->H * c->W + 255) / 256);
   RC(eae_launch_loss_finalize(st, c->msepart, nblk, nullptr, 0, 0.f, 1.0, B, c->G + c->poff[33], nullptr, nullptr));
   if (dlogits) RC(run_head(c, st, B, nullptr, nullptr, true, dlogits));
-  RC(backward_impl(c, st, &io, dz));
-  c->fwd_ready = false;
-  return 0;
+  // An eval-mode forward normalises with the running statistics: y -> gamma*(y - rm)*invstd_r + beta is affine per channel, so its
+  // backward is dy = gamma*invstd_r * g with dgamma = sum g*xhat_r, dbeta = sum g -- the same kernels with the batch-size terms
+  // (B and C of the BatchNorm-backward transform, both ~ 1/count) switched off by an infinite count.
+  c->bwd_eval = c->fwd_eval_ready;
+  if (c->bwd_eval && !(c->fold_bwd && c->sync_world <= 1))
+    return eae_set_error(EAE_ERR_STATE, "backward of an eval-mode forward needs the folded BatchNorm-backward finalize (no EAE_NO_FOLD_BWD, no SyncBN)");
+  if (c->bwd_eval) c->prebn_dirty = true;
+  const int rc = backward_impl(c, st, &io, dz);
+  c->bwd_eval = false;
+  c->fwd_ready = false; c->fwd_eval_ready = false;
+  return rc;
 }
 
 extern "C" int eae_ae_grad_step(eae_ctx* c, void* stream, const eae_step_io* io) {
@@ -1147,7 +1168,7 @@ extern "C" int eae_fp8_calibrate(eae_ctx* c, void* stream, const eae_step_io* io
   }
   EAE_HIP(hipMemcpyAsync(c->bnrun, c->bn_save, bn_bytes, hipMemcpyDeviceToDevice, st));
   if (c->nbt) EAE_HIP(hipMemcpyAsync(c->nbt, c->bn_save + c->bnoff[14], 7 * 8, hipMemcpyDeviceToDevice, st));
-  c->packed = false; c->fwd_ready = false;
+  c->packed = false; c->fwd_ready = false; c->fwd_eval_ready = false;
   return 0;
 }
 // current scales: s_act[6], s_grad[6], s_w[6] (3x3 layers in the order conv2, conv3, conv4, deconv1, deconv2, deconv3); synchronises
@@ -1183,7 +1204,7 @@ extern "C" int eae_ae_grad_step_end(eae_ctx* c, void* stream) {
   eae_step_io io = eae_step_io();
   io.x = c->fwd_x; io.B = c->fwd_B; io.train = 1; io.head = c->fwd_head;
   int rc = backward_impl(c, (hipStream_t)stream, &io, nullptr, 2);
-  c->fwd_ready = false;
+  c->fwd_ready = false; c->fwd_eval_ready = false;
   return rc;
 }
 extern "C" void* eae_side_stream(eae_ctx* c) { return c ? (void*)c->side : nullptr; }
@@ -1243,7 +1264,7 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
   RC(eae_launch_set_dyn(st, c->dyn, lr, 0.9, 0.999, 0.0, c->adam_step));
   if (ent && ent->exec) {
     EAE_HIP(hipGraphLaunch(ent->exec, st));
-    c->fwd_ready = false; c->packed = false; c->acc_clean = false;
+    c->fwd_ready = false; c->fwd_eval_ready = false; c->packed = false; c->acc_clean = false;
     return 0;
   }
   const bool capture = ent && ent->seen >= 3;      // two eager warm-up steps with this key first (lazy kernel attributes etc.)
@@ -1272,7 +1293,7 @@ extern "C" int eae_encoder_forward(eae_ctx* c, void* stream, const float* x, int
   if (!c->P || !c->bnrun) return eae_set_error(EAE_ERR_STATE, "eae_bind has not been called");
   if (B <= 0 || B > c->Bm) return eae_set_error(EAE_ERR_ARG, "batch size outside 1..max_batch");
   hipStream_t st = (hipStream_t)stream;
-  c->fwd_ready = false;
+  c->fwd_ready = false; c->fwd_eval_ready = false;
   RC(ensure_packed(c, st));
   RC(prep_accumulators(c, st, train != 0));
   RC(run_encoder(c, st, x, B, train != 0));
@@ -1284,7 +1305,7 @@ extern "C" int eae_decoder_forward(eae_ctx* c, void* stream, const float* z, int
   if (!c->P || !c->bnrun) return eae_set_error(EAE_ERR_STATE, "eae_bind has not been called");
   if (B <= 0 || B > c->Bm) return eae_set_error(EAE_ERR_ARG, "batch size outside 1..max_batch");
   hipStream_t st = (hipStream_t)stream;
-  c->fwd_ready = false;
+  c->fwd_ready = false; c->fwd_eval_ready = false;
   RC(ensure_packed(c, st));
   RC(prep_accumulators(c, st, train != 0));
   int src_rc = 0;

@@ -260,6 +260,7 @@ struct BnBwdFold {
   float inv_scale, count;
   const float* gamma; const float* coef_fwd;       // [C], [4][C]
   float* dgamma; float* dbeta; float* coef_out;    // [C], [C], [3][C]: written by the `writer` workgroup (each may be nullptr)
+  float* dbias;              // eval-mode backward only: gradient of the bias in FRONT of this BatchNorm, A[c] * sum g (train mode: zero)
 };
 template <int C>
 __device__ __forceinline__ void bn_fold_bwd_load(const BnBwdFold& f, BnFoldRegsB& r, int tid = threadIdx.x) {
@@ -291,6 +292,7 @@ __device__ __forceinline__ void bn_fold_bwd_finish(const BnBwdFold& f, const BnF
       if (f.dbeta) f.dbeta[ch] = db;
       if (f.dgamma) f.dgamma[ch] = dg;
       if (f.coef_out) { f.coef_out[ch] = A; f.coef_out[C + ch] = Bc; f.coef_out[2 * C + ch] = Cc; }
+      if (f.dbias) f.dbias[ch] = A * db;
     }
   }
   __syncthreads();

@@ -361,9 +361,9 @@ class _AEFunction(torch.autograd.Function):
     parameter gradients are returned to autograd (which accumulates them into `.grad` like for any torch module)."""
 
     @staticmethod
-    def forward(ctx, eng, x, *params):
+    def forward(ctx, eng, train, x, *params):
         x = x.contiguous()          # the backward reads the batch again (conv1 weight gradient): keep OUR copy alive, not the caller's
-        x_hat, logits, z = eng.forward(x, train=True, head=True)
+        x_hat, logits, z = eng.forward(x, train=train, head=True)
         ctx.eng = eng
         ctx.gen = eng.generation()
         ctx.save_for_backward(x, x_hat)
@@ -388,7 +388,7 @@ class _AEFunction(torch.autograd.Function):
         grads = []
         for (p, i), need in zip(eng._slots, ctx.need):
             grads.append(eng.grads[eng.poff[i]: eng.poff[i] + p.numel()].view(p.shape).clone() if need else None)
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 class _ModuleFacade:
@@ -407,10 +407,8 @@ def autoencoder_forward(module, x):
     eng = engine_for(module)
     eng.params_changed()
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        if not module.training:
-            raise RuntimeError("differentiating through an eval-mode SupervisedAutoencoder (BatchNorm with running statistics) is "
-                               "not supported by the HIP engine; call model.train() or use torch.no_grad()")
-        return _AEFunction.apply(eng, x, *[p for p, _ in eng._slots])
+        # (eval mode: BatchNorm uses the running statistics in the forward and is differentiated as the per-channel affine map it then is)
+        return _AEFunction.apply(eng, bool(module.training), x, *[p for p, _ in eng._slots])
     x_hat, logits, z = eng.forward(x, train=module.training, head=True)
     return x_hat, logits, z
 

@@ -93,11 +93,12 @@ typedef struct eae_step_io {
 
 /* x_hat, logits, z = model(x) (R.md:647 / 673), plus the loss terms when io->x target / labels are given. */
 int eae_ae_forward(eae_ctx* ctx, void* stream, const eae_step_io* io);
-/* loss.backward() for a torch-side loss (R.md:649-653): backward of the most recent train-mode eae_ae_forward given the
- * gradients of its outputs (fp32; dx_hat [B,3,H,W], dlogits [B,C] or NULL, dz [B,L] or NULL).  x = that forward's input batch
+/* loss.backward() for a torch-side loss (R.md:649-653): backward of the most recent eae_ae_forward -- train mode, or eval mode
+ * (io->train = 0: BatchNorm with the running statistics is differentiated as the per-channel affine map it then is; the biases in
+ * front of the BatchNorms then get their gradient A[c] * sum g instead of zero) -- given the gradients of its outputs (fp32; dx_hat [B,3,H,W], dlogits [B,C] or NULL, dz [B,L] or NULL).  x = that forward's input batch
  * (conv1's weight gradient reads it again: the engine keeps no pointer to caller memory across calls), x_hat = its output,
  * generation = eae_forward_generation() read right after that forward: EAE_ERR_STATE if any forward ran since.
- * Gradients of all 38 tensors land in the grad arena (biases in front of a BatchNorm: exact zeros). */
+ * Gradients of all 38 tensors land in the grad arena (train mode: biases in front of a BatchNorm are exact zeros). */
 long long eae_forward_generation(eae_ctx* ctx);
 int eae_ae_backward(eae_ctx* ctx, void* stream, long long generation, const float* x, const float* x_hat, const float* dx_hat,
                     const float* dlogits, const float* dz);

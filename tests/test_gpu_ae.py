@@ -480,6 +480,53 @@ def test_autograd_drop_in_loop_matches_fused_step(golden):
     assert torch.isfinite(xh2).all()
 
 
+def test_autograd_through_an_eval_mode_model_vs_torch_cpu_port(golden):
+    """`model.eval(); loss.backward()` (fine-tuning with frozen BatchNorm statistics): BatchNorm normalises with the running
+    statistics and is differentiated as the per-channel affine map it then is.  Gradients against torch autograd of the torch-CPU
+    port of the reference graph (oracle/ae_torch_cpu.py, itself pinned by the goldens) in eval mode; buffers untouched."""
+    import torch.nn as nn
+    import gpu_util as G
+    from oracle import ae_torch_cpu as T
+    g = golden("ae_fwd_bwd_b8.npz")
+    x, y = g["x"], g["labels"]
+    alpha = float(g["alpha"])
+    sd = ae_state_np()
+    p = T.build(state=sd)
+    m = _model()
+    m.eval()
+    rv_before = m.enc.encoder[1].running_var.detach().clone()
+    xh, lg, z = m(_cuda(x))
+    loss = alpha * nn.MSELoss()(xh, _cuda(x)) + nn.CrossEntropyLoss()(lg, _cuda(y))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(rv_before, m.enc.encoder[1].running_var) and int(m.enc.encoder[1].num_batches_tracked) == 0
+    # reference: the same graph in torch on the CPU, eval mode
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    xr, lr_, _ = T.forward(p, xt, train=False)
+    lref = alpha * nn.functional.mse_loss(xr, xt) + nn.functional.cross_entropy(lr_, yt)
+    lref.backward()
+    assert abs(float(loss) - float(lref)) <= 0.02 * abs(float(lref))
+    assert np.abs(xh.detach().cpu().numpy() - xr.detach().numpy()).max() <= 3e-2
+    bad = []
+    for name, prm in m.named_parameters():
+        ref = p[name].grad.numpy()
+        got = prm.grad.cpu().numpy()
+        # (in eval mode a bias in front of a BatchNorm DOES get a gradient: the normalisation no longer removes it)
+        c = G.cosine(got, ref)
+        ratio = np.linalg.norm(got) / max(np.linalg.norm(ref), 1e-30)
+        if not (c > 0.97 and 0.9 <= ratio <= 1.1):
+            bad.append((name, round(c, 4), round(float(ratio), 3)))
+    assert not bad, bad
+    # a train-mode gradient step afterwards: the biases in front of the BatchNorms have an identically zero gradient again
+    eng = _engine(m)
+    eng.grad_step(_cuda(x), _cuda(y), alpha)
+    torch.cuda.synchronize()
+    eng.expose_grads()
+    for name, prm in m.named_parameters():
+        if gu.is_prebn_bias(name):
+            assert float(prm.grad.abs().max()) == 0.0, name
+
+
 def test_autograd_temporary_noncontiguous_input_and_stale_forward(golden):
     """The backward reads the input batch again (conv1's weight gradient).  It must be the autograd node's own saved copy: a
     temporary (`model(imgs + noise)`) or a non-contiguous input is gone when backward runs, and the allocator hands its memory
