@@ -79,6 +79,7 @@ struct eae_ctx {
   bool packed = false;
   bool fwd_ready = false;          // a train-mode forward with gradient staging is resident in the workspace
   bool fwd_eval_ready = false;     // ... or an eval-mode one (BatchNorm with running statistics): eae_ae_backward differentiates that too
+  int enc_ready = 0, dec_ready = 0; // stand-alone eae_encoder_forward / eae_decoder_forward resident: 0 no, 1 train mode, 2 eval mode
   bool bwd_eval = false;           // the running backward differentiates an eval-mode forward: BatchNorm is a per-channel affine map
   bool prebn_dirty = false;        // an eval-mode backward wrote the gradients of the biases in front of the BatchNorms (train mode: zero)
   int fwd_B = 0, fwd_head = 0;
@@ -331,6 +332,8 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   e = hipMemcpy(c->descs_dev, descs.data(), descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(c->g4, 0, Bm * (size_t)c->H * c->W * 4 * 2);
   if (e == hipSuccess && c->lpad) e = hipMemset(c->zstage, 0, Bm * (size_t)c->Lp * 4);
+  if (e == hipSuccess) e = hipMemset(c->z, 0, Bm * (size_t)c->Lp * 4);
+  if (e == hipSuccess) e = hipMemset(c->dz, 0, Bm * (size_t)c->Lp * 4);
   if (e == hipSuccess) e = hipMemset(c->acc_base, 0, c->acc_bytes);
   if (e == hipSuccess) e = hipMemset(c->sigwords, 0, 64);
   c->acc_clean = true;
@@ -429,7 +432,7 @@ extern "C" int eae_destroy(eae_ctx* c) {
 extern "C" int eae_bind(eae_ctx* c, float* params, float* grads, float* adam_m, float* adam_v, float* bn_running, long long* bn_nbt) {
   if (!c || !params || !bn_running) return eae_set_error(EAE_ERR_ARG, "bind: ctx, params and bn_running are required");
   c->P = params; c->G = grads; c->M = adam_m; c->V = adam_v; c->bnrun = bn_running; c->nbt = bn_nbt;
-  c->packed = false; c->fwd_ready = false; c->fwd_eval_ready = false;
+  c->packed = false; c->fwd_ready = false; c->fwd_eval_ready = false; c->enc_ready = 0; c->dec_ready = 0;
   if (grads)
     for (int k = 0; k < 7; ++k)
       EAE_HIP(hipMemset(grads + c->poff[PREBN_BIAS[k]], 0, (size_t)(c->poff[PREBN_BIAS[k] + 1] - c->poff[PREBN_BIAS[k]]) * 4));
@@ -462,7 +465,7 @@ extern "C" long long eae_gate_timeouts(eae_ctx* c) {
   if (hipMemcpy(&v, c->sigwords + 8, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (long long)v;
 }
-extern "C" int eae_params_changed(eae_ctx* c) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->packed = false; c->fwd_ready = false; c->fwd_eval_ready = false; return 0; }
+extern "C" int eae_params_changed(eae_ctx* c) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->packed = false; c->fwd_ready = false; c->fwd_eval_ready = false; c->enc_ready = 0; c->dec_ready = 0; return 0; }
 extern "C" int eae_set_adam_step(eae_ctx* c, long long s) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->adam_step = s; return 0; }
 extern "C" long long eae_get_adam_step(eae_ctx* c) { return c ? c->adam_step : -1; }
 
@@ -721,6 +724,11 @@ int copy_latent_out(eae_ctx* c, hipStream_t st, float* dst, const float* src_pad
   EAE_HIP(hipMemcpy2DAsync(dst, (size_t)c->L * 4, src_padded, (size_t)c->Lp * 4, (size_t)c->L * 4, B, hipMemcpyDeviceToDevice, st));
   return 0;
 }
+int copy_latent_in(eae_ctx* c, hipStream_t st, float* dst_padded, const float* src, int B) {      // padding columns of dst stay as they are (zero)
+  if (!c->lpad) { EAE_HIP(hipMemcpyAsync(dst_padded, src, (size_t)B * c->L * 4, hipMemcpyDeviceToDevice, st)); return 0; }
+  EAE_HIP(hipMemcpy2DAsync(dst_padded, (size_t)c->Lp * 4, src, (size_t)c->L * 4, (size_t)c->L * 4, B, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
 const float* stage_latent_in(eae_ctx* c, hipStream_t st, const float* src, int B, int* rc) {
   *rc = 0;
   if (!c->lpad || !src) return src;
@@ -844,7 +852,7 @@ int check_io(eae_ctx* c, const eae_step_io* io, bool need_grad) {
 int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_grad) {
   const int B = io->B;
   const bool train = io->train != 0;
-  c->fwd_ready = train; c->fwd_eval_ready = !train; c->fwd_B = B; c->fwd_head = io->head; c->fwd_x = io->x; c->fwd_gen += 1;
+  c->fwd_ready = train; c->fwd_eval_ready = !train; c->enc_ready = 0; c->dec_ready = 0; c->fwd_B = B; c->fwd_head = io->head; c->fwd_x = io->x; c->fwd_gen += 1;
   RC(ensure_packed(c, st));
   RC(prep_accumulators(c, st, train));
   RC(run_encoder(c, st, io->x, B, train));
@@ -1136,7 +1144,7 @@ extern "C" int eae_ae_backward(eae_ctx* c, void* stream, long long generation, c
   if (c->bwd_eval) c->prebn_dirty = true;
   const int rc = backward_impl(c, st, &io, dz);
   c->bwd_eval = false;
-  c->fwd_ready = false; c->fwd_eval_ready = false;
+  c->fwd_ready = false; c->fwd_eval_ready = false; c->enc_ready = 0; c->dec_ready = 0;
   return rc;
 }
 
@@ -1168,7 +1176,7 @@ extern "C" int eae_fp8_calibrate(eae_ctx* c, void* stream, const eae_step_io* io
   }
   EAE_HIP(hipMemcpyAsync(c->bnrun, c->bn_save, bn_bytes, hipMemcpyDeviceToDevice, st));
   if (c->nbt) EAE_HIP(hipMemcpyAsync(c->nbt, c->bn_save + c->bnoff[14], 7 * 8, hipMemcpyDeviceToDevice, st));
-  c->packed = false; c->fwd_ready = false; c->fwd_eval_ready = false;
+  c->packed = false; c->fwd_ready = false; c->fwd_eval_ready = false; c->enc_ready = 0; c->dec_ready = 0;
   return 0;
 }
 // current scales: s_act[6], s_grad[6], s_w[6] (3x3 layers in the order conv2, conv3, conv4, deconv1, deconv2, deconv3); synchronises
@@ -1204,7 +1212,7 @@ extern "C" int eae_ae_grad_step_end(eae_ctx* c, void* stream) {
   eae_step_io io = eae_step_io();
   io.x = c->fwd_x; io.B = c->fwd_B; io.train = 1; io.head = c->fwd_head;
   int rc = backward_impl(c, (hipStream_t)stream, &io, nullptr, 2);
-  c->fwd_ready = false; c->fwd_eval_ready = false;
+  c->fwd_ready = false; c->fwd_eval_ready = false; c->enc_ready = 0; c->dec_ready = 0;
   return rc;
 }
 extern "C" void* eae_side_stream(eae_ctx* c) { return c ? (void*)c->side : nullptr; }
@@ -1264,7 +1272,7 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
   RC(eae_launch_set_dyn(st, c->dyn, lr, 0.9, 0.999, 0.0, c->adam_step));
   if (ent && ent->exec) {
     EAE_HIP(hipGraphLaunch(ent->exec, st));
-    c->fwd_ready = false; c->fwd_eval_ready = false; c->packed = false; c->acc_clean = false;
+    c->fwd_ready = false; c->fwd_eval_ready = false; c->enc_ready = 0; c->dec_ready = 0; c->packed = false; c->acc_clean = false;
     return 0;
   }
   const bool capture = ent && ent->seen >= 3;      // two eager warm-up steps with this key first (lazy kernel attributes etc.)
@@ -1293,11 +1301,62 @@ extern "C" int eae_encoder_forward(eae_ctx* c, void* stream, const float* x, int
   if (!c->P || !c->bnrun) return eae_set_error(EAE_ERR_STATE, "eae_bind has not been called");
   if (B <= 0 || B > c->Bm) return eae_set_error(EAE_ERR_ARG, "batch size outside 1..max_batch");
   hipStream_t st = (hipStream_t)stream;
-  c->fwd_ready = false; c->fwd_eval_ready = false;
+  c->fwd_ready = false; c->fwd_eval_ready = false; c->enc_ready = 0; c->dec_ready = 0;
   RC(ensure_packed(c, st));
   RC(prep_accumulators(c, st, train != 0));
   RC(run_encoder(c, st, x, B, train != 0));
+  c->enc_ready = train ? 1 : 2; c->fwd_B = B; c->fwd_gen += 1;
   return copy_latent_out(c, st, z, c->z, B);
+}
+
+namespace {
+int half_backward_checks(eae_ctx* c, int ready, long long generation) {
+  if (!c || !c->G) return eae_set_error(EAE_ERR_STATE, "backward: no gradient arena bound");
+  if (!ready) return eae_set_error(EAE_ERR_STATE, "backward: the matching stand-alone forward is not resident");
+  if (generation != c->fwd_gen)
+    return eae_set_error(EAE_ERR_STATE, "backward: a later forward has replaced the activations of the forward being differentiated");
+  if (ready == 2 && !(c->fold_bwd && c->sync_world <= 1))
+    return eae_set_error(EAE_ERR_STATE, "backward of an eval-mode forward needs the folded BatchNorm-backward finalize (no EAE_NO_FOLD_BWD, no SyncBN)");
+  return 0;
+}
+}  // namespace
+
+// Backward of a stand-alone Encoder (z = enc(x); ... ; z.backward(dz)): the encoder half of the gradient step for an externally supplied
+// dL/dz [B][L].  x = the forward's input batch (conv1's weight gradient reads it), generation as for eae_ae_backward.
+extern "C" int eae_encoder_backward(eae_ctx* c, void* stream, long long generation, const float* x, const float* dz) {
+  RC(half_backward_checks(c, c ? c->enc_ready : 0, generation));
+  if (!x || !dz) return eae_set_error(EAE_ERR_ARG, "encoder_backward: x and dz are required");
+  hipStream_t st = (hipStream_t)stream;
+  RC(copy_latent_in(c, st, c->dz, dz, c->fwd_B));
+  eae_step_io io = eae_step_io();
+  io.x = x; io.B = c->fwd_B; io.train = 1; io.head = 0;
+  c->bwd_eval = c->enc_ready == 2;
+  if (c->bwd_eval) c->prebn_dirty = true;
+  const int rc = backward_impl(c, st, &io, nullptr, 2);
+  c->bwd_eval = false;
+  c->enc_ready = 0;
+  return rc;
+}
+
+// Backward of a stand-alone Decoder (x_hat = dec(z); ... ; x_hat.backward(dx_hat)): decoder + dec.fc gradients and dL/dz -> dz_out [B][L].
+extern "C" int eae_decoder_backward(eae_ctx* c, void* stream, long long generation, const float* x_hat, const float* dx_hat, float* dz_out) {
+  RC(half_backward_checks(c, c ? c->dec_ready : 0, generation));
+  if (!x_hat || !dx_hat) return eae_set_error(EAE_ERR_ARG, "decoder_backward: x_hat and dx_hat are required");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = c->fwd_B;
+  eae_step_io io = eae_step_io();
+  io.B = B; io.train = 1; io.head = 0;
+  RC(eae_launch_sigmoid_bwd(st, x_hat, dx_hat, c->g4, c->msepart, B, c->H, c->W));
+  const int nblk = (int)(((long long)B * c->H * c->W + 255) / 256);
+  RC(eae_launch_loss_finalize(st, c->msepart, nblk, nullptr, 0, 0.f, 1.0, B, c->G + c->poff[33], nullptr, nullptr));
+  c->bwd_eval = c->dec_ready == 2;
+  if (c->bwd_eval) c->prebn_dirty = true;
+  int rc = backward_impl(c, st, &io, nullptr, 1);
+  c->bwd_eval = false;
+  c->dec_ready = 0;
+  if (!rc) rc = join_side(c, st);
+  if (!rc && dz_out) rc = copy_latent_out(c, st, dz_out, c->dz, B);
+  return rc;
 }
 
 extern "C" int eae_decoder_forward(eae_ctx* c, void* stream, const float* z, int B, int train, float* x_hat) {
@@ -1305,13 +1364,13 @@ extern "C" int eae_decoder_forward(eae_ctx* c, void* stream, const float* z, int
   if (!c->P || !c->bnrun) return eae_set_error(EAE_ERR_STATE, "eae_bind has not been called");
   if (B <= 0 || B > c->Bm) return eae_set_error(EAE_ERR_ARG, "batch size outside 1..max_batch");
   hipStream_t st = (hipStream_t)stream;
-  c->fwd_ready = false; c->fwd_eval_ready = false;
+  c->fwd_ready = false; c->fwd_eval_ready = false; c->enc_ready = 0; c->dec_ready = 0;
   RC(ensure_packed(c, st));
   RC(prep_accumulators(c, st, train != 0));
-  int src_rc = 0;
-  const float* zp = stage_latent_in(c, st, z, B, &src_rc);
-  RC(src_rc);
-  return run_decoder(c, st, zp, B, train != 0, nullptr, 0.f, x_hat, false, false);
+  RC(copy_latent_in(c, st, c->z, z, B));       // resident for the backward (dec.fc's weight gradient reads z again)
+  RC(run_decoder(c, st, c->z, B, train != 0, nullptr, 0.f, x_hat, false, false));
+  c->dec_ready = train ? 1 : 2; c->fwd_B = B; c->fwd_gen += 1;
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------- per-op wrappers

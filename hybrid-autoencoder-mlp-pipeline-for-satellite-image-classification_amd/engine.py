@@ -391,16 +391,46 @@ class _AEFunction(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
-class _ModuleFacade:
-    """What the nn.Module shells call (modules.py).  Inference / no-grad forward of the reference signatures."""
+class _HalfFunction(torch.autograd.Function):
+    """Autograd through a stand-alone Encoder (half = "enc": z = enc(x)) or Decoder (half = "dec": x_hat = dec(z)), e.g. a plain
+    autoencoder composed by hand, `x_hat = dec(enc(x))`.  forward = eae_encoder_forward / eae_decoder_forward, backward =
+    eae_encoder_backward / eae_decoder_backward; only the parameters of that half receive gradients."""
 
     @staticmethod
-    def _check_grad(module, *tensors):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-            raise RuntimeError(
-                "autograd through a stand-alone Encoder / Decoder is not supported by the HIP engine: differentiate through the "
-                "owning SupervisedAutoencoder (R.md:647), use fit_autoencoder / AEEngine.train_step, or call forward under "
-                "torch.no_grad()")
+    def forward(ctx, eng, half, train, inp, *params):
+        inp = inp.contiguous()
+        out = eng.encoder(inp, train=train) if half == "enc" else eng.decoder(inp, train=train)
+        ctx.eng, ctx.half, ctx.gen = eng, half, eng.generation()
+        ctx.save_for_backward(inp, out)
+        ctx.slots = [(p, i) for p, i in eng._slots if (i < 18 if half == "enc" else 18 <= i < 34)]
+        ctx.need = [p.requires_grad for p in params]
+        ctx.need_input = inp.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng = ctx.eng
+        inp, out = ctx.saved_tensors
+        dout = dout.to(dtype=torch.float32).contiguous()
+        din = None
+        with torch.cuda.device(eng.device):
+            if ctx.half == "enc":
+                check(eng.lib.eae_encoder_backward(eng.ctx, _stream(), ctx.gen, _ptr(inp), _ptr(dout)))     # (no dL/dx: images are leaves)
+            else:
+                din = torch.empty_like(inp) if ctx.need_input else None
+                check(eng.lib.eae_decoder_backward(eng.ctx, _stream(), ctx.gen, _ptr(out), _ptr(dout), _ptr(din)))
+        grads = [eng.grads[eng.poff[i]: eng.poff[i] + p.numel()].view(p.shape).clone() if need else None
+                 for (p, i), need in zip(ctx.slots, ctx.need)]
+        return (None, None, None, din, *grads)
+
+
+def _half_forward(module, inp, half):
+    eng = engine_for(module)
+    eng.params_changed()
+    slots = [p for p, i in eng._slots if (i < 18 if half == "enc" else 18 <= i < 34)]
+    if torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in slots)):
+        return _HalfFunction.apply(eng, half, bool(module.training), inp, *slots)
+    return eng.encoder(inp, train=module.training) if half == "enc" else eng.decoder(inp, train=module.training)
 
 
 def autoencoder_forward(module, x):
@@ -414,14 +444,8 @@ def autoencoder_forward(module, x):
 
 
 def encoder_forward(module, x):
-    _ModuleFacade._check_grad(module)
-    eng = engine_for(module)
-    eng.params_changed()
-    return eng.encoder(x, train=module.training)
+    return _half_forward(module, x, "enc")
 
 
 def decoder_forward(module, z):
-    _ModuleFacade._check_grad(module)
-    eng = engine_for(module)
-    eng.params_changed()
-    return eng.decoder(z, train=module.training)
+    return _half_forward(module, z, "dec")

@@ -135,6 +135,12 @@ int eae_ae_train_step(eae_ctx* ctx, void* stream, const eae_step_io* io, float l
 int eae_encoder_forward(eae_ctx* ctx, void* stream, const float* x, int B, int train, float* z);
 /* Decoder alone (Decoder.forward, R.md:386-389). */
 int eae_decoder_forward(eae_ctx* ctx, void* stream, const float* z, int B, int train, float* x_hat);
+/* loss.backward() through a stand-alone Encoder / Decoder (the notebook defines them as separate modules, R.md:287, 361; e.g.
+ * x_hat = dec(enc(x)) with an MSE loss): backward of the most recent eae_encoder_forward / eae_decoder_forward (train or eval mode)
+ * for an externally supplied gradient of its output.  generation = eae_forward_generation() right after that forward.
+ * encoder: dz [B][L], x = the forward's input;  decoder: dx_hat [B,3,H,W], x_hat = the forward's output, dz_out [B][L] (may be NULL). */
+int eae_encoder_backward(eae_ctx* ctx, void* stream, long long generation, const float* x, const float* dz);
+int eae_decoder_backward(eae_ctx* ctx, void* stream, long long generation, const float* x_hat, const float* dx_hat, float* dz_out);
 
 /* In-situ timing of ONE launch site inside real train steps (bench.py's `roofline` object): HIP events are recorded around that
  * launch, on the stream it goes to, for up to 64 steps; eae_profile_read2 synchronises them and returns the summed bracket time,

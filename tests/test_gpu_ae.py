@@ -527,6 +527,47 @@ def test_autograd_through_an_eval_mode_model_vs_torch_cpu_port(golden):
             assert float(prm.grad.abs().max()) == 0.0, name
 
 
+def test_autograd_through_stand_alone_encoder_and_decoder(golden):
+    """The notebook defines Encoder and Decoder as modules of their own (R.md:287, 361).  A plain autoencoder composed by hand,
+    `x_hat = dec(enc(x))` with an MSE loss and loss.backward(), must give the gradients of the fused reconstruction-only step
+    (head=False, alpha=1) of a SupervisedAutoencoder holding the same weights: same kernels, only the loss gradient comes from torch."""
+    import torch.nn as nn
+    import eae_amd
+    g = golden("ae_fwd_bwd_b8.npz")
+    x = _cuda(g["x"])
+    sd = ae_state_np()
+    m = _model()
+    e = _engine(m)
+    e.grad_step(x, _cuda(g["labels"]), 1.0, head=False)
+    e.expose_grads()
+    ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+    enc, dec = eae_amd.Encoder(latent_dim=64), eae_amd.Decoder(latent_dim=64)
+    load_state_np(enc, {k[4:]: v for k, v in sd.items() if k.startswith("enc.")})
+    load_state_np(dec, {k[4:]: v for k, v in sd.items() if k.startswith("dec.")})
+    enc, dec = enc.cuda().train(), dec.cuda().train()
+    z = enc(x)
+    assert z.requires_grad and tuple(z.shape) == (8, 64)
+    x_hat = dec(z)
+    loss = nn.MSELoss()(x_hat, x)
+    loss.backward()
+    torch.cuda.synchronize()
+    for mod, prefix in ((enc, "enc."), (dec, "dec.")):
+        for n, p in mod.named_parameters():
+            a, b = ref[prefix + n].cpu().numpy(), p.grad.cpu().numpy()
+            scale = max(1e-12, np.abs(a).max())
+            assert np.abs(a - b).max() <= 2e-2 * scale, (prefix + n, np.abs(a - b).max() / scale)
+    # a second forward before the backward invalidates the first one's activations: raises instead of differentiating the wrong batch
+    z1 = enc(x)
+    _ = enc(x)
+    with pytest.raises(Exception, match="later forward"):
+        z1.sum().backward()
+    # no-grad / eval use is unchanged (extract_features' call shape, R.md:2504)
+    enc.eval()
+    with torch.no_grad():
+        z2 = enc(x)
+    assert not z2.requires_grad and torch.isfinite(z2).all()
+
+
 def test_autograd_temporary_noncontiguous_input_and_stale_forward(golden):
     """The backward reads the input batch again (conv1's weight gradient).  It must be the autograd node's own saved copy: a
     temporary (`model(imgs + noise)`) or a non-contiguous input is gone when backward runs, and the allocator hands its memory
