@@ -141,6 +141,44 @@ def config5_leg(batch=128, steps=20, warmup=5):
     return res
 
 
+def grid_b64_leg(k=8, steps=150, warmup=15):
+    """The reference's REAL workload (R.md:246, 599-711): batch 64, a grid of independent configurations.  K engine contexts, each on
+    its own stream and stepped from its own host thread (train.run_concurrent -- what grid_search_autoencoder(concurrent=K) uses), run
+    the joint train step at B=64 at the same time; `images_per_s` is the aggregate over the K configurations, `k1` the same loop with
+    one configuration."""
+    import eae_amd
+    from eae_amd.engine import engine_for
+    from eae_amd import train as T
+    res = {"workload": "BASELINE configs[2]'s step at the notebook's batch size 64 (R.md:246): K independent (alpha, lr) configurations of "
+                       "the grid R.md:599-711 trained concurrently on one GPU, one engine context + stream + host thread each", "batch": 64}
+    x, y = make_batch(64, torch.device("cuda"), seed=4321)
+    for kk in (1, k):
+        engs = []
+        for i in range(kk):
+            torch.manual_seed(100 + i)
+            m = eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=10).cuda().train()
+            engs.append((m, engine_for(m, max_batch=64)))
+
+        def job_of(e, n):
+            def job():
+                for _ in range(n):
+                    e.train_step(x, y, ALPHA, 1e-3)
+            return job
+        T.run_concurrent([job_of(e, warmup) for _, e in engs], kk)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        T.run_concurrent([job_of(e, steps) for _, e in engs], kk)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        bad = [e.gate_timeouts() for _, e in engs]
+        res["k1" if kk == 1 else "concurrent"] = {"configs": kk, "steps_each": steps, "images_per_s": round(kk * steps * 64 / el, 1),
+                                                  "ms_per_step_per_config": round(1e3 * el / steps, 4), "gate_timeouts": sum(1 for b in bad if b)}
+        del engs
+        torch.cuda.empty_cache()
+    res["images_per_s"] = res["concurrent"]["images_per_s"]
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -259,6 +297,11 @@ def main():
                 out.setdefault("configs", {})["c5"] = config5_leg()
             except Exception as e:
                 out.setdefault("configs", {})["c5"] = {"error": str(e)[:200]}
+            try:
+                out.setdefault("configs", {})["grid_b64"] = grid_b64_leg()
+                out["configs"]["grid_b64"]["vs_b512_single_model"] = round(out["configs"]["grid_b64"]["images_per_s"] / value, 3)
+            except Exception as e:
+                out.setdefault("configs", {})["grid_b64"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

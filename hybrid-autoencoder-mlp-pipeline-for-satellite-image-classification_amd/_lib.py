@@ -37,6 +37,8 @@ _PROTOS = {
     "eae_destroy": (C.c_int, [vp]),
     "eae_bind": (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
     "eae_gate_timeouts": (C.c_longlong, [vp]),
+    "eae_gate_timeouts_clear": (C.c_int, [vp]),
+    "eae_gate_timeouts_nosync": (C.c_longlong, [vp]),
     "eae_encoder_backward": (C.c_int, [vp, vp, C.c_longlong, vp, vp]),
     "eae_decoder_backward": (C.c_int, [vp, vp, C.c_longlong, vp, vp, vp]),
     "eae_fp8_calibrate": (C.c_int, [vp, vp, vp, C.c_int]),

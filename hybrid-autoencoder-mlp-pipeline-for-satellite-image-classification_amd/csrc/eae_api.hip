@@ -137,6 +137,8 @@ struct eae_ctx {
   unsigned side_done_seq[1 + MAXX] = {};
   unsigned side_used = 0;          // bit k: side stream k received work since the last join
   bool use_gates = true;           // device-side gates instead of event records on the caller's stream (EAE_FORK_EVENTS=1: events)
+  unsigned long long gate_limit = 3000000000ULL;     // gate spin bound in 100 MHz ticks (30 s; EAE_GATE_TIMEOUT_MS, 0 = unbounded)
+  float* last_loss = nullptr;      // the caller's loss_last buffer of the most recent step: poisoned with NaN when a gate has timed out
   hipStream_t own_main = nullptr;  // capture is not permitted on the legacy default stream: graphs run here, bracketed by events
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   static constexpr int NEV = 16;
@@ -243,14 +245,14 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
       if (const char* e = getenv("EAE_ACC_COPIES_MAX")) { int mx = atoi(e); while (mx >= 1 && cp > mx) cp /= 2; }
       c->acc_copies[l] = cp;
       o_acc[l] = acc_total;
-      acc_total += (size_t)cp * 2 * BN_C[l] * 8;
+      acc_total += (size_t)cp * 2 * BN_C[l] * 8 + (size_t)BN_C[l] * 8;        // + the layer's [C] sticky non-finite flag words (BnAcc::flag)
     }
   }
   size_t o_accb = carve(2 * acc_total);  // forward accumulators, then the backward ones (cleared together)   // conv1 weight gradient (last kernel of the backward, runs on the main stream)
   const int ksplit = (int)(c->K / 128);
   size_t o_fcp = carve((size_t)ksplit * Bm * c->Lp * 4);
   size_t o_mse = carve(std::max((size_t)eae_edge_tiles((int)Bm, c->H, c->W), (size_t)((Bm * c->H * c->W + 255) / 256)) * 4 * 4);
-  const long long hb = eae_head_blocks((int)Bm);
+  const long long hb = eae_head_blocks((int)Bm, 256);     // (the narrow-row variant of wide latents has the most blocks)
   c->head_stride = r4(128LL * c->Lp) + 128 + r4(128LL * c->C) + r4(c->C);
   size_t o_gsew = 0, o_gseb = 0, o_gsdw = 0, o_gsh = 0, o_zst = 0;
   if (c->lpad) {
@@ -326,6 +328,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   // kernel at a time on the device: under it (ROCPROF_COUNTER_COLLECTION=1 in the environment) the hand-overs fall back to events.
   const char* rcc = getenv("ROCPROF_COUNTER_COLLECTION");
   c->use_gates = getenv("EAE_FORK_EVENTS") == nullptr && !(rcc && atoi(rcc) != 0);
+  if (const char* gt = getenv("EAE_GATE_TIMEOUT_MS")) c->gate_limit = (unsigned long long)(atof(gt) * 1e5);
   // hipGraph replay is opt-in (EAE_GRAPH=1): on ROCm 7.2 the replayed graph ran its two branches one after the other
   // (0.80 ms/step) while the eager two-stream launch sequence overlaps them (0.71 ms/step)
   c->use_graph = getenv("EAE_GRAPH") != nullptr && getenv("EAE_NO_GRAPH") == nullptr;
@@ -458,6 +461,22 @@ extern "C" int eae_set_sync_bn(eae_ctx* c, int world, eae_sync_fn fn, void* user
 }
 // Diagnostic (synchronises the device): 0, or the progress value a gate kernel gave up waiting for after its bounded spin
 // (include/eae.h); the step in which that happened produced wrong gradients.
+// Clear the sticky time-out word (after the caller has dealt with the failed step); synchronises the device.
+extern "C" int eae_gate_timeouts_clear(eae_ctx* c) {
+  if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL");
+  EAE_HIP(hipDeviceSynchronize());
+  EAE_HIP(hipMemset(c->sigwords + 8, 0, 4));
+  return 0;
+}
+// The same word WITHOUT synchronising the device: for callers that have just synchronised the stream they step on (every gate of
+// a completed step has run by then) and share the device with other contexts -- the concurrent grid driver (train.py) must not
+// stall every configuration at each epoch end of one of them.
+extern "C" long long eae_gate_timeouts_nosync(eae_ctx* c) {
+  if (!c) return -1;
+  unsigned v = 0;
+  if (hipMemcpy(&v, c->sigwords + 8, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (long long)v;
+}
 extern "C" long long eae_gate_timeouts(eae_ctx* c) {
   if (!c) return -1;
   unsigned v = 0;
@@ -558,7 +577,7 @@ int sq_commit(eae_ctx* c, hipStream_t st) {
       c->pending_sig = 0;
     }
     GateArgs g = GateArgs();
-    g.word[0] = c->sigwords; g.want[0] = c->sq_wait; g.n = 1; g.timeout = c->sigwords + 8;
+    g.word[0] = c->sigwords; g.want[0] = c->sq_wait; g.n = 1; g.timeout = c->sigwords + 8; g.limit_ticks = c->gate_limit;
     for (int k = 0; k < ns; ++k) if (used & (1u << k)) RC(eae_launch_gate(side_stream(c, k), g));
   } else {
     hipEvent_t ev = c->ev_fork[c->ev_i];
@@ -591,7 +610,7 @@ int join_side(eae_ctx* c, hipStream_t st) {
   const int ns = 1 + c->nx;
   if (gates_now(c)) {
     GateArgs g = GateArgs();
-    g.timeout = c->sigwords + 8;
+    g.timeout = c->sigwords + 8; g.limit_ticks = c->gate_limit;
     for (int k = 0; k < ns; ++k) {
       if (!(c->side_used & (1u << k))) continue;
       c->side_done_seq[k] += 1;
@@ -624,6 +643,8 @@ SrcDesc src_bnrelu(const bf16_t* y, const float* coef) { SrcDesc s; s.p0 = y; s.
 SrcDesc src_bnbwd(const bf16_t* g, const bf16_t* y, const float* coef) { SrcDesc s; s.p0 = g; s.p1 = y; s.coef = coef; return s; }
 SrcDesc src_f32(const float* p) { SrcDesc s; s.p0 = reinterpret_cast<const bf16_t*>(p); s.p1 = nullptr; s.coef = nullptr; return s; }
 
+// the [C] sticky non-finite flag words of BN layer l sit behind the layer's [acc_copies][2][C] accumulators (forward or backward half)
+unsigned long long* acc_flag(const eae_ctx* c, unsigned long long* acc, int l) { return acc + (size_t)c->acc_copies[l] * 2 * BN_C[l]; }
 constexpr float ACC_SCALE_FWD = 16777216.f;      // 2^24: sums of y and y^2 over <= 2^21 elements of |y| <~ 1e3 stay far below 2^63
 
 // fp8 variant: weight pack, scales and the amax word of 3x3 layer j (W3 order) for a forward / backward-data launch
@@ -637,7 +658,7 @@ void fp8_conv_args(eae_ctx* c, ConvArgs& a, int j, bool forward, bool p1) {
 // producer side of the folded forward finalize of BN layer l
 void fold_producer(eae_ctx* c, ConvArgs& a, int l, bool train) {
   if (!train || !c->fold_fwd) return;
-  a.bacc.acc = c->accf[l]; a.bacc.copies = c->acc_copies[l]; a.bacc.scale = ACC_SCALE_FWD;
+  a.bacc.acc = c->accf[l]; a.bacc.copies = c->acc_copies[l]; a.bacc.scale = ACC_SCALE_FWD; a.bacc.flag = acc_flag(c, c->accf[l], l);
   a.stat_part = nullptr;
 }
 // consumer side: coefficient table of BN layer l from its accumulators
@@ -647,7 +668,7 @@ int sync_fwd(eae_ctx* c, hipStream_t st, int l, bool train) {
   if (!train || c->sync_world <= 1) return 0;
   if (!c->fold_fwd) return eae_set_error(EAE_ERR_STATE, "SyncBN needs the folded forward finalize (unset EAE_NO_FOLD_FWD)");
   const long long off = (long long)(c->accf[l] - reinterpret_cast<unsigned long long*>(c->acc_base));
-  if (c->sync_fn(c->sync_user, 0, off, (long long)c->acc_copies[l] * 2 * BN_C[l], (void*)st) != 0)
+  if (c->sync_fn(c->sync_user, 0, off, (long long)c->acc_copies[l] * 2 * BN_C[l] + BN_C[l], (void*)st) != 0)      // (+C: the non-finite flag words)
     return eae_set_error(EAE_ERR_STATE, "SyncBN: the exchange hook failed (forward statistics)");
   return 0;
 }
@@ -655,7 +676,7 @@ void fold_consumer(eae_ctx* c, BnFold& f, int l, long long count, bool train) {
   f = BnFold();
   if (!train || !c->fold_fwd) return;
   count *= c->sync_world;
-  f.acc = c->accf[l]; f.copies = c->acc_copies[l]; f.inv_scale = 1.0f / ACC_SCALE_FWD; f.count = (float)count;
+  f.acc = c->accf[l]; f.copies = c->acc_copies[l]; f.inv_scale = 1.0f / ACC_SCALE_FWD; f.count = (float)count; f.flag = acc_flag(c, c->accf[l], l);
   f.momentum = BN_MOM; f.eps = BN_EPS;
   f.gamma = c->P + c->poff[BN_GAMMA_IDX[l]]; f.beta = c->P + c->poff[BN_GAMMA_IDX[l] + 1];
   f.rm = c->bnrun + c->bnoff[2 * l]; f.rv = c->bnrun + c->bnoff[2 * l + 1]; f.nbt = c->nbt ? c->nbt + l : nullptr;
@@ -688,14 +709,14 @@ int bwd_copies(const eae_ctx* c, int l) { return std::min(c->acc_copies[l], BN_F
 void fold_bwd_producer(eae_ctx* c, ConvArgs& a, int l) {
   if (!bwd_folded(c, l)) return;
   a.stat_part = nullptr;
-  a.bacc.acc = c->accb[l]; a.bacc.copies = bwd_copies(c, l); a.bacc.scale = ACC_SCALE_BWD;
+  a.bacc.acc = c->accb[l]; a.bacc.copies = bwd_copies(c, l); a.bacc.scale = ACC_SCALE_BWD; a.bacc.flag = acc_flag(c, c->accb[l], l);
 }
 // consumer side: the kernels that read layer l's (g, y) pair with SRC_BNBWD build A, B, Cc from the accumulators; `writer`: the
 // main-stream consumer, whose workgroup 0 also stores dgamma / dbeta and the table
 void fold_bwd_consumer(eae_ctx* c, BnBwdFold& f, int l, long long count, bool writer) {
   f = BnBwdFold();
   if (!bwd_folded(c, l)) return;
-  f.acc = c->accb[l]; f.copies = bwd_copies(c, l); f.inv_scale = 1.0f / ACC_SCALE_BWD;
+  f.acc = c->accb[l]; f.copies = bwd_copies(c, l); f.inv_scale = 1.0f / ACC_SCALE_BWD; f.flag = acc_flag(c, c->accb[l], l);
   f.count = c->bwd_eval ? __builtin_inff() : (float)count;
   f.gamma = c->P + c->poff[BN_GAMMA_IDX[l]]; f.coef_fwd = c->coef_f[l];
   if (writer) {
@@ -853,6 +874,7 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
   const int B = io->B;
   const bool train = io->train != 0;
   c->fwd_ready = train; c->fwd_eval_ready = !train; c->enc_ready = 0; c->dec_ready = 0; c->fwd_B = B; c->fwd_head = io->head; c->fwd_x = io->x; c->fwd_gen += 1;
+  if (want_grad) c->last_loss = io->loss_last;
   RC(ensure_packed(c, st));
   RC(prep_accumulators(c, st, train));
   RC(run_encoder(c, st, io->x, B, train));
@@ -880,7 +902,7 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
   RC(run_decoder(c, st, c->z, B, train, (want_loss || want_grad) ? io->x : nullptr, gscale, io->x_hat, want_grad, want_loss));
   if (io->z) RC(copy_latent_out(c, st, io->z, c->z, B));
   if (want_loss || want_grad) {
-    const int n_ce = (head && io->labels) ? eae_head_blocks(B) : 0;
+    const int n_ce = (head && io->labels) ? eae_head_blocks(B, c->Lp) : 0;
     // in a gradient step nothing on the main stream reads what this kernel writes (deconv4 bias gradient, loss scalars):
     // it goes to the side stream, which backward_impl joins before the optimizer
     if (want_grad && c->use_side) {
@@ -921,7 +943,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     c->side_rr = 1;                // the round robin of the later groups starts at side stream #1
     if (head) {
       sq_push(c, [=](hipStream_t ss, float*) {
-        const int nb = eae_head_blocks(B);
+        const int nb = eae_head_blocks(B, c->Lp);
         hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(c->head_stride / 4)), dim3(256), 0, ss, c->headpart, nb,
                            (long)(c->head_stride / 4), c->lpad ? c->gs_head : c->G + c->poff[34], 1.0f);
         EAE_LAUNCH_CHECK();
@@ -1194,7 +1216,7 @@ extern "C" int eae_adam_step(eae_ctx* c, void* stream, float lr, float weight_de
   if (!c || !c->P || !c->G || !c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: parameter, gradient and moment arenas must be bound");
   c->adam_step += 1;
   RC(eae_launch_adam_scaled((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step, 1.0f,
-                            c->acc_base, (long long)c->acc_bytes));
+                            c->acc_base, (long long)c->acc_bytes, c->sigwords + 8, c->last_loss));
   c->packed = false; c->acc_clean = true;
   return 0;
 }
@@ -1231,7 +1253,7 @@ extern "C" int eae_adam_step_scaled(eae_ctx* c, void* stream, float lr, float we
   if (!c || !c->P || !c->G || !c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: parameter, gradient and moment arenas must be bound");
   c->adam_step += 1;
   RC(eae_launch_adam_scaled((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step, grad_scale,
-                            c->acc_base, (long long)c->acc_bytes));
+                            c->acc_base, (long long)c->acc_bytes, c->sigwords + 8, c->last_loss));
   c->packed = false; c->acc_clean = true;
   return 0;
 }
@@ -1265,7 +1287,7 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
     int rc = forward_impl(c, st, io, true);
     if (!rc) rc = backward_impl(c, st, io);
     if (!rc) rc = eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f,
-                                         c->acc_base, (long long)c->acc_bytes);
+                                         c->acc_base, (long long)c->acc_bytes, c->sigwords + 8, c->last_loss);
     c->packed = false; c->acc_clean = (rc == 0);
     return rc;
   }
@@ -1280,7 +1302,7 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
   c->capturing = capture;
   int rc = forward_impl(c, st, io, true);
   if (!rc) rc = backward_impl(c, st, io);
-  if (!rc) rc = eae_launch_adam_dyn(st, c->P, c->G, c->M, c->V, c->poff[38], 0.9, 0.999, 1e-8, c->dyn);
+  if (!rc) rc = eae_launch_adam_dyn(st, c->P, c->G, c->M, c->V, c->poff[38], 0.9, 0.999, 1e-8, c->dyn, c->sigwords + 8, c->last_loss);
   c->capturing = false;
   c->packed = false;
   if (capture) {
@@ -1480,7 +1502,7 @@ extern "C" int eae_op_fc_wgrad(void* stream, int mode, eae_src p, eae_src q, int
 }
 static long long head_stride_of(int L, int C) { return r4(128LL * L) + 128 + r4(128LL * C) + r4(C); }
 extern "C" long long eae_op_head_scratch_floats(int B, int L, int C) {
-  return (long long)eae_head_blocks(B) * (head_stride_of(L, C) + 2) + 64;
+  return (long long)eae_head_blocks(B, L) * (head_stride_of(L, C) + 2) + 64;
 }
 extern "C" int eae_op_head_ce(void* stream, const float* z, const float* w1, const float* b1, const float* w2, const float* b2,
                               const long long* labels, int B, int L, int C, float* logits, float* dz, float* grads, float* loss2,
@@ -1489,7 +1511,7 @@ extern "C" int eae_op_head_ce(void* stream, const float* z, const float* w1, con
   if (scratch_floats < eae_op_head_scratch_floats(B, L, C)) return eae_set_error(EAE_ERR_ARG, "head_ce: scratch too small");
   hipStream_t st = (hipStream_t)stream;
   const long long stride = head_stride_of(L, C);
-  const int nb = eae_head_blocks(B);
+  const int nb = eae_head_blocks(B, L);
   float* ce_part = scratch;                         // [nb][2]
   float* gpart = scratch + (((long long)nb * 2 + 3) & ~3LL);
   HeadArgs h = HeadArgs();

@@ -153,11 +153,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* row_ptr_lo, const bf16_t
 //             over 256 threads) and builds the coefficient table in LDS; workgroup 0 also stores the table for the kernels
 //             that need it later and updates the running statistics.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr long long BN_ACC_POISON = 1LL << 61;
 struct BnAcc {
   unsigned long long* acc;   // [copies][2][C]; zero before the producer runs; nullptr: per-tile partials + finalize kernel
   int copies;                // power of two
   float scale;               // fixed-point scale
+  unsigned long long* flag;  // [C] sticky "a non-finite partial of this channel was seen" words (cleared with the accumulators)
 };
 struct BnFold {
   const unsigned long long* acc;   // nullptr: the coefficients come from SrcDesc::coef
@@ -166,29 +166,32 @@ struct BnFold {
   const float* gamma; const float* beta;
   float* rm; float* rv; long long* nbt;
   float* coef_out;           // [4][C]: s, t, mean, invstd
+  const unsigned long long* flag;  // [C] the layer's non-finite flags (BnAcc::flag)
 };
 __device__ __forceinline__ void bn_acc_add(const BnAcc& b, int C, int tile_id, int which, int ch, float v) {
   unsigned long long* p = b.acc + ((size_t)(tile_id & (b.copies - 1)) * 2 + which) * C + ch;
-  // a non-finite partial (diverged run) must poison the statistics like it does in floating point: it is added as 2^61, which
-  // no finite data can reach, and the consumer turns such a sum back into NaN
+  // a non-finite partial (diverged run) must poison the statistics like it does in floating point.  It cannot travel inside the
+  // wrapping integer sum (round 2 added 2^61 per poisoned partial: eight of them -- every workgroup of a diverged step -- cancel
+  // mod 2^64): it sets the channel's sticky flag word instead, and the consumers turn a set flag into NaN coefficients of that channel
   const float sv = v * b.scale;
-  const long long q = (fabsf(sv) < 9.0e18f) ? llrintf(sv) : BN_ACC_POISON;
-  __hip_atomic_fetch_add(p, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fabsf(sv) < 9.0e18f) __hip_atomic_fetch_add(p, (unsigned long long)llrintf(sv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else if (b.flag != nullptr) __hip_atomic_fetch_or(b.flag + ch, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Split in two so that the accumulator loads can be ISSUED before the kernel's own first loads (vector-memory results return in
 // issue order: a prologue whose loads queue behind the patch loads would wait for all of them) and CONSUMED after those are in
 // flight.  copies <= 4 * (256 / C)  (at most 4 accumulator sets per thread).
 constexpr int BN_FOLD_K = 4;
 constexpr int BN_FOLD_KB = 2;      // backward tables: the consumers hold two source tensors' raw pieces in registers meanwhile
-template <int K> struct BnFoldRegsT { long long v[2][K]; };
+template <int K> struct BnFoldRegsT { long long v[2][K]; unsigned long long flag; };
 typedef BnFoldRegsT<BN_FOLD_K> BnFoldRegs;
 typedef BnFoldRegsT<BN_FOLD_KB> BnFoldRegsB;
 // `tid` = index of the calling thread among the 256 threads that build the table (default: the whole 256-thread workgroup)
 template <int C, int K>
-__device__ __forceinline__ void bn_fold_load_acc(const unsigned long long* acc, int copies, BnFoldRegsT<K>& r, int tid) {
+__device__ __forceinline__ void bn_fold_load_acc(const unsigned long long* acc, int copies, const unsigned long long* flag, BnFoldRegsT<K>& r, int tid) {
   static_assert(C <= 256 && 256 % C == 0, "channel count");
   constexpr int G = 256 / C;
   const int ch = tid % C, grp = tid / C;
+  r.flag = flag != nullptr ? flag[ch] : 0ull;
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     const int k = grp + j * G;
@@ -199,7 +202,7 @@ __device__ __forceinline__ void bn_fold_load_acc(const unsigned long long* acc, 
 }
 template <int C>
 __device__ __forceinline__ void bn_fold_load(const BnFold& f, BnFoldRegs& r, int tid = threadIdx.x) {
-  bn_fold_load_acc<C, BN_FOLD_K>(f.acc, f.copies, r, tid);
+  bn_fold_load_acc<C, BN_FOLD_K>(f.acc, f.copies, f.flag, r, tid);
 }
 // All 256 threads of the workgroup.  table = LDS float [4][C]; red = LDS long long [2][256] (may alias any idle buffer).
 // (contains two workgroup barriers: every wave of the workgroup has to pass them, table builders or not)
@@ -216,7 +219,7 @@ __device__ __forceinline__ void bn_fold_fwd_finish(const BnFold& f, const BnFold
   if (grp == 0) {
 #pragma unroll
     for (int g = 1; g < G; ++g) { s1 += red[g * C + ch]; s2 += red[256 + g * C + ch]; }
-    const bool poisoned = s1 >= (BN_ACC_POISON >> 1) || s1 <= -(BN_ACC_POISON >> 1) || s2 >= (BN_ACC_POISON >> 1) || s2 <= -(BN_ACC_POISON >> 1);
+    const bool poisoned = r.flag != 0ull;
     const double a = poisoned ? (double)__builtin_nanf("") : (double)s1 * (double)f.inv_scale, b = (double)s2 * (double)f.inv_scale;
     const double mean = a / f.count;
     double var = b / f.count - mean * mean;
@@ -261,10 +264,11 @@ struct BnBwdFold {
   const float* gamma; const float* coef_fwd;       // [C], [4][C]
   float* dgamma; float* dbeta; float* coef_out;    // [C], [C], [3][C]: written by the `writer` workgroup (each may be nullptr)
   float* dbias;              // eval-mode backward only: gradient of the bias in FRONT of this BatchNorm, A[c] * sum g (train mode: zero)
+  const unsigned long long* flag;  // [C] the layer's non-finite flags (BnAcc::flag of the backward accumulators)
 };
 template <int C>
 __device__ __forceinline__ void bn_fold_bwd_load(const BnBwdFold& f, BnFoldRegsB& r, int tid = threadIdx.x) {
-  bn_fold_load_acc<C, BN_FOLD_KB>(f.acc, f.copies, r, tid);     // copies <= BN_FOLD_KB * (256 / C)
+  bn_fold_load_acc<C, BN_FOLD_KB>(f.acc, f.copies, f.flag, r, tid);     // copies <= BN_FOLD_KB * (256 / C)
 }
 // 256 threads (tid 0..255).  table = LDS float [3][C]; red = LDS long long [2][256] (may alias any idle buffer).  Two barriers.
 template <int C>
@@ -280,7 +284,7 @@ __device__ __forceinline__ void bn_fold_bwd_finish(const BnBwdFold& f, const BnF
   if (grp == 0) {
 #pragma unroll
     for (int g = 1; g < G; ++g) { s1 += red[g * C + ch]; s2 += red[256 + g * C + ch]; }
-    const bool poisoned = s1 >= (BN_ACC_POISON >> 1) || s1 <= -(BN_ACC_POISON >> 1) || s2 >= (BN_ACC_POISON >> 1) || s2 <= -(BN_ACC_POISON >> 1);
+    const bool poisoned = r.flag != 0ull;
     const float db = poisoned ? __builtin_nanf("") : (float)((double)s1 * (double)f.inv_scale);
     const float dg = (float)((double)s2 * (double)f.inv_scale);
     const float mean = f.coef_fwd[2 * C + ch], invstd = f.coef_fwd[3 * C + ch];

@@ -147,9 +147,15 @@ static __global__ EAE_NO_PK __launch_bounds__(256) void fc_splitk_reduce_kernel(
   const long i = (long)blockIdx.x * 16 + lx;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n4)
-    for (int k = ly; k < nsl; k += 16) {
-      float4 v = reinterpret_cast<const float4*>(part)[(long)k * n4 + i];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    for (int k0 = ly; k0 < nsl; k0 += 16 * 4) {          // 4 loads in flight, summed in slice order
+      float4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + 16 * q;
+        v[q] = k < nsl ? reinterpret_cast<const float4*>(part)[(long)k * n4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { s.x += v[q].x; s.y += v[q].y; s.z += v[q].z; s.w += v[q].w; }
     }
   red[ly][lx] = s;
   __syncthreads();
@@ -178,6 +184,41 @@ struct FcTnArgs {
   int out_mode, Pn;        // Pn = pixels per image of the flattened map
 };
 
+// raw 16-byte piece of 8 consecutive operand elements as it comes back from memory (fp32 sources: two float4), and its transform
+template <int MODE> struct FcRaw { uint4 v; };
+template <> struct FcRaw<SRC_F32> { float4 lo, hi; };
+template <int MODE>
+__device__ __forceinline__ void fc_load_raw(const SrcDesc& s, size_t off, bool valid, FcRaw<MODE>& r) {
+  if constexpr (MODE == SRC_F32) {
+    const float* f = reinterpret_cast<const float*>(s.p0) + off;
+    r.lo = valid ? *reinterpret_cast<const float4*>(f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    r.hi = valid ? *reinterpret_cast<const float4*>(f + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    r.v = valid ? *reinterpret_cast<const uint4*>(s.p0 + off) : make_uint4(0, 0, 0, 0);
+  }
+}
+template <int MODE>
+__device__ __forceinline__ uint4 fc_finish_raw(const FcRaw<MODE>& r, bool valid, const float* cs, const float* ct) {
+  if constexpr (MODE == SRC_F32) {
+    float v[8] = {r.lo.x, r.lo.y, r.lo.z, r.lo.w, r.hi.x, r.hi.y, r.hi.z, r.hi.w};
+    return pack8(v);
+  } else if constexpr (MODE == SRC_BNRELU) {
+    if (!valid) return make_uint4(0, 0, 0, 0);
+    float x[8];
+    unpack8(r.v, x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = fmaxf(fmaf(cs[j], x[j], ct[j]), 0.f);
+    return pack8(x);
+  } else {
+    return r.v;
+  }
+}
+
+// The reduction runs over the batch in chunks of 64 rows; one block walks ALL chunks, so its time used to be (number of chunks) x
+// (memory latency + staging + a handful of MFMAs): 8 exposed round trips at B=512 (22 us inside the step for 8 MB of operands).  The raw
+// pieces of the next FC_TN_D chunks are now kept in flight in a register ring (compile-time slots), the transform / LDS staging of chunk
+// c runs when its pieces have arrived, and the slot is re-issued for chunk c + FC_TN_D before the MFMAs of chunk c.
+constexpr int FC_TN_D = 4;
 template <int PMODE, int QMODE>
 __global__ __launch_bounds__(256) void fc_tn_kernel(FcTnArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t pl[64 * FC_LS];
@@ -193,34 +234,59 @@ __global__ __launch_bounds__(256) void fc_tn_kernel(FcTnArgs a) {
   float cs[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) cs[j] = 0.f;
-  for (int b0 = 0; b0 < a.Bt; b0 += 64) {
-    if (b0) __syncthreads();
-    uint4 pv[2], qv[2];
+  // BatchNorm-apply coefficients of this thread's 8 channels (fixed over the batch loop)
+  float pcs[8], pct[8], qcs[8], qct[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    pcs[j] = pct[j] = qcs[j] = qct[j] = 0.f;
+    if (PMODE == SRC_BNRELU) { const int ch = ((i0 + kg8 * 8) & 255) + j; pcs[j] = a.p.coef[ch]; pct[j] = a.p.coef[256 + ch]; }
+    if (QMODE == SRC_BNRELU) { const int ch = ((j0 + kg8 * 8) & 255) + j; qcs[j] = a.q.coef[ch]; qct[j] = a.q.coef[256 + ch]; }
+  }
+  const int nchunks = (a.Bt + 63) / 64;
+  FcRaw<PMODE> rp[FC_TN_D][2];
+  FcRaw<QMODE> rq[FC_TN_D][2];
+  auto issue = [&](FcRaw<PMODE> (&xp)[2], FcRaw<QMODE> (&xq)[2], int b0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int row = (tid + i * 256) >> 3;
-      bool v = (b0 + row) < a.Bt;
-      pv[i] = fc_load_a<PMODE>(a.p, (size_t)(b0 + row) * a.I + i0 + kg8 * 8, v, a.p.coef, (i0 + kg8 * 8) & 255);
-      qv[i] = fc_load_a<QMODE>(a.q, (size_t)(b0 + row) * a.J + j0 + kg8 * 8, v, a.q.coef, (j0 + kg8 * 8) & 255);
-      float f[8];
-      unpack8(pv[i], f);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) cs[j] += f[j];
+      const int row = (tid + i * 256) >> 3;
+      const bool v = (b0 + row) < a.Bt;
+      fc_load_raw<PMODE>(a.p, (size_t)(b0 + row) * a.I + i0 + kg8 * 8, v, xp[i]);
+      fc_load_raw<QMODE>(a.q, (size_t)(b0 + row) * a.J + j0 + kg8 * 8, v, xq[i]);
     }
+  };
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<uint4*>(pl + ((tid + i * 256) >> 3) * FC_LS + kg8 * 8) = pv[i];
-      *reinterpret_cast<uint4*>(ql + ((tid + i * 256) >> 3) * FC_LS + kg8 * 8) = qv[i];
-    }
-    __syncthreads();
+  for (int d = 0; d < FC_TN_D; ++d)
+    if (d < nchunks) issue(rp[d], rq[d], d * 64);
+  for (int c0 = 0; c0 < nchunks; c0 += FC_TN_D) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int r_lo = ks * 32 + 8 * g + q, r_hi = r_lo + 4;
-      bf16x8 pa = tr_frag(pl + r_lo * FC_LS + wave * 16 + 4 * p, pl + r_hi * FC_LS + wave * 16 + 4 * p);
+    for (int d = 0; d < FC_TN_D; ++d) {
+      const int c = c0 + d;
+      if (c >= nchunks) break;                         // uniform over the block
+      if (c) __syncthreads();                          // the previous chunk's fragment reads are done
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        bf16x8 qb = tr_frag(ql + r_lo * FC_LS + jt * 16 + 4 * p, ql + r_hi * FC_LS + jt * 16 + 4 * p);
-        acc[jt] = mfma16(pa, qb, acc[jt]);
+      for (int i = 0; i < 2; ++i) {
+        const int row = (tid + i * 256) >> 3;
+        const bool v = (c * 64 + row) < a.Bt;
+        const uint4 pv = fc_finish_raw<PMODE>(rp[d][i], v, pcs, pct);
+        const uint4 qv = fc_finish_raw<QMODE>(rq[d][i], v, qcs, qct);
+        float f[8];
+        unpack8(pv, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] += f[j];
+        *reinterpret_cast<uint4*>(pl + row * FC_LS + kg8 * 8) = pv;
+        *reinterpret_cast<uint4*>(ql + row * FC_LS + kg8 * 8) = qv;
+      }
+      if (c + FC_TN_D < nchunks) issue(rp[d], rq[d], (c + FC_TN_D) * 64);
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int r_lo = ks * 32 + 8 * g + q, r_hi = r_lo + 4;
+        bf16x8 pa = tr_frag(pl + r_lo * FC_LS + wave * 16 + 4 * p, pl + r_hi * FC_LS + wave * 16 + 4 * p);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+          bf16x8 qb = tr_frag(ql + r_lo * FC_LS + jt * 16 + 4 * p, ql + r_hi * FC_LS + jt * 16 + 4 * p);
+          acc[jt] = mfma16(pa, qb, acc[jt]);
+        }
       }
     }
   }
@@ -237,6 +303,7 @@ __global__ __launch_bounds__(256) void fc_tn_kernel(FcTnArgs a) {
     }
   if (a.colsum && blockIdx.y == 0) {
     // thread (row-group tid>>3, chunk kg8) holds partial column sums of its rows; reduce over the 32 row-groups
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) csum[tid >> 3][kg8 * 8 + j] = cs[j];
     __syncthreads();

@@ -1,60 +1,93 @@
 // Classification head of SupervisedAutoencoder (R.md:423-427): Linear(L,128) -> ReLU -> Linear(128,C), fused with
 // CrossEntropyLoss (R.md:623, 650) and the whole backward of the head, in fp32 (9.5 K MAC per image: pure latency).
-// One block handles HR = 8 batch rows: forward, softmax/CE, dlogits, dh, dz and the per-block partial weight gradients,
+// One block handles 16 (8 for wide latents) batch rows: forward, softmax/CE, dlogits, dh, dz and the per-block partial weight gradients,
 // which are laid out exactly like the four head tensors in the parameter arena so one reduce_slices call finishes them.
 #include "eae_internal.h"
 #include "eae_common.hip.h"
 #include "eae_head.h"
+#include <utility>
+#include <vector>
 
-constexpr int HR = 8;   // batch rows per block
 constexpr int HC = 64;  // logits row stride in LDS = largest class count
 
+// Round 3: the round-2 kernel (8 rows per block, every operand read from LDS one float at a time, W1 staged with scalar loads and
+// an integer division per element) took 38-40 us for 19 K MAC per image.  Now: HR_ = 16 rows per block (8 when the latent is wider
+// than 128: W1 alone is then 130 KB of LDS), 16-byte global and LDS accesses, and every product register-blocked so that an LDS
+// float4 feeds 8-32 FMAs:
+//   h_pre [HR][128] = z W1^T        thread = 2 rows x 4 columns (j, j+32, j+64, j+96), K in steps of 4
+//   dz    [HR][L]   = dh W1         thread = 1 row x 4 consecutive k (strided over [HR][L/4]), j = 0..127
+//   dW1   [128][L]  = dh^T z        thread = 8 j x 4 k tiles (strided over [16][L/4]), r = 0..HR-1
+// Row strides are padded to L + 4 / 132 floats: 16-byte aligned rows whose float4 reads by 16 consecutive lanes fall on 16 different
+// bank slots.  Arithmetic stays fp32 fmaf chains (the head is fp32 end to end: <= 5e-5 vs the reference's goldens).
+template <int HR_>
 __global__ EAE_NO_PK __launch_bounds__(256) void head_kernel(HeadArgs a) {
-  extern __shared__ float sm[];
-  const int L = a.L, C = a.C, LS = L + 1;
-  float* w1 = sm;                    // [128][L+1]
-  float* zt = w1 + 128 * LS;         // [HR][L]
-  float* w2 = zt + HR * L;           // [C][128]
-  float* hp = w2 + C * 128;          // [32][129]  pre-activation
-  float* dh = hp + HR * 129;         // [HR][129]
-  float* lg = dh + HR * 129;         // [HR][HC]   logits, then dlogits
-  float* b1 = lg + HR * HC;          // [128]
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int L = a.L, C = a.C, LS = L + 4, HS = 132;
+  float* w1 = sm;                    // [128][LS]
+  float* zt = w1 + 128 * LS;         // [HR_][LS]
+  float* w2 = zt + HR_ * LS;         // [C][HS]
+  float* hp = w2 + ((C * HS + 3) & ~3);   // [HR_][HS]  pre-activation
+  float* dh = hp + HR_ * HS;         // [HR_][HS]
+  float* lg = dh + HR_ * HS;         // [HR_][HC]   logits, then dlogits
+  float* b1 = lg + HR_ * HC;         // [128]
   float* b2 = b1 + 128;              // [HC]
-  float* rl = b2 + HC;               // [HR] per-row loss, [HR] per-row correct
+  float* rl = b2 + HC;               // [HR_] per-row loss, [HR_] per-row correct
   const int tid = threadIdx.x;
-  const int r0 = blockIdx.x * HR;
-  for (int i = tid; i < 128 * L; i += 256) w1[(i / L) * LS + (i % L)] = a.w1[i];
-  for (int i = tid; i < HR * L; i += 256) {
-    int r = r0 + i / L;
-    zt[i] = r < a.B ? a.z[(size_t)r * L + (i % L)] : 0.f;
+  const int r0 = blockIdx.x * HR_;
+  const int L4 = L >> 2;
+  for (int i = tid; i < 128 * L4; i += 256) {
+    const int j = i / L4, k4 = i - j * L4;
+    *reinterpret_cast<float4*>(w1 + j * LS + k4 * 4) = *reinterpret_cast<const float4*>(a.w1 + (size_t)j * L + k4 * 4);
   }
-  for (int i = tid; i < C * 128; i += 256) w2[i] = a.w2[i];
+  for (int i = tid; i < HR_ * L4; i += 256) {
+    const int r = i / L4, k4 = i - r * L4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < a.B) v = *reinterpret_cast<const float4*>(a.z + (size_t)(r0 + r) * L + k4 * 4);
+    *reinterpret_cast<float4*>(zt + r * LS + k4 * 4) = v;
+  }
+  for (int i = tid; i < C * 32; i += 256) {
+    const int c = i >> 5, j4 = i & 31;
+    *reinterpret_cast<float4*>(w2 + c * HS + j4 * 4) = *reinterpret_cast<const float4*>(a.w2 + (size_t)c * 128 + j4 * 4);
+  }
   if (tid < 128) b1[tid] = a.b1[tid];
   if (tid < C) b2[tid] = a.b2[tid];
   __syncthreads();
-  {   // h_pre[r][j]
-    const int j = tid & 127, rh = tid >> 7;
-    constexpr int RH = HR / 2;
-    float accv[RH];
+  {   // h_pre[r][j]: 2 rows x 4 columns per thread
+    constexpr int RT = HR_ / 2;                 // row pairs
+    const int ct = tid & 31, rt = tid >> 5;     // 8 row groups x 32 column groups
+    if (rt < RT) {
+      float acc[2][4];
 #pragma unroll
-    for (int r = 0; r < RH; ++r) accv[r] = b1[j];
-    for (int k = 0; k < L; ++k) {
-      float w = w1[j * LS + k];
+      for (int q = 0; q < 4; ++q) { acc[0][q] = b1[ct + 32 * q]; acc[1][q] = acc[0][q]; }
+#pragma unroll 4
+      for (int k = 0; k < L; k += 4) {
+        const float4 z0 = *reinterpret_cast<const float4*>(zt + (2 * rt) * LS + k), z1 = *reinterpret_cast<const float4*>(zt + (2 * rt + 1) * LS + k);
 #pragma unroll
-      for (int r = 0; r < RH; ++r) accv[r] = fmaf(zt[(rh * RH + r) * L + k], w, accv[r]);
+        for (int q = 0; q < 4; ++q) {
+          const float4 w = *reinterpret_cast<const float4*>(w1 + (ct + 32 * q) * LS + k);
+          acc[0][q] = fmaf(z0.x, w.x, acc[0][q]); acc[0][q] = fmaf(z0.y, w.y, acc[0][q]);
+          acc[0][q] = fmaf(z0.z, w.z, acc[0][q]); acc[0][q] = fmaf(z0.w, w.w, acc[0][q]);
+          acc[1][q] = fmaf(z1.x, w.x, acc[1][q]); acc[1][q] = fmaf(z1.y, w.y, acc[1][q]);
+          acc[1][q] = fmaf(z1.z, w.z, acc[1][q]); acc[1][q] = fmaf(z1.w, w.w, acc[1][q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { hp[(2 * rt) * HS + ct + 32 * q] = acc[0][q]; hp[(2 * rt + 1) * HS + ct + 32 * q] = acc[1][q]; }
     }
-#pragma unroll
-    for (int r = 0; r < RH; ++r) hp[(rh * RH + r) * 129 + j] = accv[r];
   }
   __syncthreads();
-  for (int i = tid; i < HR * C; i += 256) {   // logits
-    int r = i / C, c = i % C;
+  for (int i = tid; i < HR_ * C; i += 256) {   // logits
+    const int r = i / C, c = i - r * C;
     float s = b2[c];
-    for (int j = 0; j < 128; ++j) s = fmaf(fmaxf(hp[r * 129 + j], 0.f), w2[c * 128 + j], s);
+#pragma unroll 8
+    for (int j = 0; j < 128; j += 4) {
+      const float4 h = *reinterpret_cast<const float4*>(hp + r * HS + j), w = *reinterpret_cast<const float4*>(w2 + c * HS + j);
+      s = fmaf(fmaxf(h.x, 0.f), w.x, s); s = fmaf(fmaxf(h.y, 0.f), w.y, s); s = fmaf(fmaxf(h.z, 0.f), w.z, s); s = fmaf(fmaxf(h.w, 0.f), w.w, s);
+    }
     lg[r * HC + c] = s;
   }
   __syncthreads();
-  if (tid < HR) {   // softmax + CE per row
+  if (tid < HR_) {   // softmax + CE per row
     int r = r0 + tid;
     float loss = 0.f, correct = 0.f;
     if (r < a.B) {
@@ -79,66 +112,103 @@ __global__ EAE_NO_PK __launch_bounds__(256) void head_kernel(HeadArgs a) {
     } else {
       for (int c = 0; c < C; ++c) lg[tid * HC + c] = 0.f;
     }
-    rl[tid] = loss; rl[HR + tid] = correct;
+    rl[tid] = loss; rl[HR_ + tid] = correct;
   }
   __syncthreads();
   if (tid == 0 && a.loss_part) {
     float s = 0.f, cr = 0.f;
-    for (int r = 0; r < HR; ++r) { s += rl[r]; cr += rl[HR + r]; }
+    for (int r = 0; r < HR_; ++r) { s += rl[r]; cr += rl[HR_ + r]; }
     a.loss_part[blockIdx.x * 2] = s; a.loss_part[blockIdx.x * 2 + 1] = cr;
   }
   if ((!a.labels && !a.dlogits_in) || !a.grad_part) return;
-  {   // dh[r][j] = (h_pre > 0) * sum_c dlogits[r][c] * W2[c][j]
-    const int j = tid & 127, rh = tid >> 7;
-    for (int r = rh * (HR / 2); r < (rh + 1) * (HR / 2); ++r) {
-      float s = 0.f;
-      for (int c = 0; c < C; ++c) s = fmaf(lg[r * HC + c], w2[c * 128 + j], s);
-      dh[r * 129 + j] = hp[r * 129 + j] > 0.f ? s : 0.f;
-    }
+  // dh[r][j] = (h_pre > 0) * sum_c dlogits[r][c] * W2[c][j]
+  for (int i = tid; i < HR_ * 128; i += 256) {
+    const int r = i >> 7, j = i & 127;
+    float s = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) s = fmaf(lg[r * HC + c], w2[c * HS + j], s);
+    dh[r * HS + j] = hp[r * HS + j] > 0.f ? s : 0.f;
   }
   __syncthreads();
-  // dz_cls[r][k] = sum_j dh[r][j] * W1[j][k]
-  for (int i = tid; i < HR * L; i += 256) {
-    int r = i / L, k = i % L;
-    float s = 0.f;
-    for (int j = 0; j < 128; ++j) s = fmaf(dh[r * 129 + j], w1[j * LS + k], s);
-    if (r0 + r < a.B) a.dz[(size_t)(r0 + r) * L + k] = s;
+  // dz_cls[r][k..k+3] = sum_j dh[r][j] * W1[j][k..k+3]
+  for (int i = tid; i < HR_ * L4; i += 256) {
+    const int r = i / L4, k4 = i - r * L4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < 128; j += 8) {        // 10 LDS reads in flight per 32 FMAs (a one-read-per-iteration loop exposes the LDS latency 128 times)
+      const float4 d0 = *reinterpret_cast<const float4*>(dh + r * HS + j), d1 = *reinterpret_cast<const float4*>(dh + r * HS + j + 4);
+      const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      float4 w[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const float4*>(w1 + (j + q) * LS + k4 * 4);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        s.x = fmaf(d[q], w[q].x, s.x); s.y = fmaf(d[q], w[q].y, s.y); s.z = fmaf(d[q], w[q].z, s.z); s.w = fmaf(d[q], w[q].w, s.w);
+      }
+    }
+    if (r0 + r < a.B) *reinterpret_cast<float4*>(a.dz + (size_t)(r0 + r) * L + k4 * 4) = s;
   }
   // partial weight gradients of this block, arena order: W1 [128][L], b1 [128], W2 [C][128], b2 [C] (+pad)
   float* gp = a.grad_part + (size_t)blockIdx.x * a.grad_stride;
-  for (int i = tid; i < 128 * L; i += 256) {
-    int j = i / L, k = i % L;
-    float s = 0.f;
-    for (int r = 0; r < HR; ++r) s = fmaf(dh[r * 129 + j], zt[r * L + k], s);
-    gp[i] = s;
+  for (int i = tid; i < 16 * L4; i += 256) {            // dW1: tiles of 8 j x 4 k
+    const int jt = i / L4, k4 = i - jt * L4;
+    float4 s[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int r = 0; r < HR_; ++r) {
+      const float4 zv = *reinterpret_cast<const float4*>(zt + r * LS + k4 * 4);
+      const float4 d0 = *reinterpret_cast<const float4*>(dh + r * HS + jt * 8), d1 = *reinterpret_cast<const float4*>(dh + r * HS + jt * 8 + 4);
+      const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        s[q].x = fmaf(d[q], zv.x, s[q].x); s[q].y = fmaf(d[q], zv.y, s[q].y); s[q].z = fmaf(d[q], zv.z, s[q].z); s[q].w = fmaf(d[q], zv.w, s[q].w);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(gp + (size_t)(jt * 8 + q) * L + k4 * 4) = s[q];
   }
   if (tid < 128) {
     float s = 0.f;
-    for (int r = 0; r < HR; ++r) s += dh[r * 129 + tid];
+    for (int r = 0; r < HR_; ++r) s += dh[r * HS + tid];
     gp[128 * L + tid] = s;
   }
   for (int i = tid; i < C * 128; i += 256) {
-    int c = i / 128, j = i % 128;
+    int c = i >> 7, j = i & 127;
     float s = 0.f;
-    for (int r = 0; r < HR; ++r) s = fmaf(lg[r * HC + c], fmaxf(hp[r * 129 + j], 0.f), s);
+#pragma unroll
+    for (int r = 0; r < HR_; ++r) s = fmaf(lg[r * HC + c], fmaxf(hp[r * HS + j], 0.f), s);
     gp[128 * L + 128 + i] = s;
   }
   if (tid < ((C + 3) & ~3)) {
     float s = 0.f;
-    if (tid < C) for (int r = 0; r < HR; ++r) s += lg[r * HC + tid];
+    if (tid < C) for (int r = 0; r < HR_; ++r) s += lg[r * HC + tid];
     gp[128 * L + 128 + C * 128 + tid] = s;
   }
 }
 
+static int head_rows(int L) { return L <= 128 ? 16 : 8; }
+int eae_head_blocks(int B, int L) { const int hr = head_rows(L); return (B + hr - 1) / hr; }
+
 int eae_launch_head(hipStream_t st, const HeadArgs& a) {
   if (a.L > 256 || a.C > HC || a.L % 4) return eae_set_error(-2, "head: latent_dim must be <= 256 (multiple of 4), classes <= 64");
-  size_t smem = sizeof(float) * ((size_t)128 * (a.L + 1) + HR * a.L + a.C * 128 + 2 * HR * 129 + HR * HC + 128 + HC + 2 * HR);
-  static size_t attr = 0;
-  if (smem > attr) {
-    EAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr = smem;
+  const int hr = head_rows(a.L);
+  const size_t smem = sizeof(float) * ((size_t)128 * (a.L + 4) + (size_t)hr * (a.L + 4) + ((a.C * 132 + 3) & ~3) + 2 * hr * 132 + hr * HC + 128 + HC + 2 * hr);
+  // the dynamic-LDS limit is an attribute of the kernel ON ONE DEVICE and the request grows with the latent width: keep the
+  // largest size granted per (kernel, device) (a process-wide static skipped the attribute for an engine on a second device)
+  void (*kern)(HeadArgs) = hr == 16 ? head_kernel<16> : head_kernel<8>;
+  {
+    static thread_local std::vector<std::pair<std::pair<const void*, int>, size_t>> granted;
+    int dev = 0;
+    EAE_HIP(hipGetDevice(&dev));
+    const void* f = reinterpret_cast<const void*>(kern);
+    size_t* have = nullptr;
+    for (auto& g : granted) if (g.first.first == f && g.first.second == dev) have = &g.second;
+    if (!have || *have < smem) {
+      EAE_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      if (have) *have = smem; else granted.push_back({{f, dev}, smem});
+    }
   }
-  hipLaunchKernelGGL(head_kernel, dim3((a.B + HR - 1) / HR), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3((a.B + hr - 1) / hr), dim3(256), smem, st, a);
   EAE_LAUNCH_CHECK();
   return 0;
 }
@@ -149,28 +219,45 @@ int eae_launch_head(hipStream_t st, const HeadArgs& a) {
 //   accum[0] += loss*B, accum[1] += mse*B, accum[2] += ce*B, accum[3] += B, accum[4] += correct
 //   last[0..2] = loss, mse, ce of this step
 // ---------------------------------------------------------------------------------------------------------------
+// fixed-order reduction: xor butterfly inside each wave (every lane ends with the wave's sum), the four wave sums added in wave order
+__device__ __forceinline__ double lf_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 __global__ EAE_NO_PK __launch_bounds__(256) void loss_finalize_kernel(const float* mse_part, int n_mse, const float* ce_part, int n_ce, float alpha,
                                                              float inv_numel, float B, float* db4, float* accum, float* last) {
-  __shared__ double red[256][6];
+  __shared__ double red[4][6];
   const int tid = threadIdx.x;
   double s[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = tid; i < n_mse; i += 256) {
-    float4 v = reinterpret_cast<const float4*>(mse_part)[i];
-    s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+  // 8 loads in flight per thread: with one load per loop iteration every iteration exposed a full memory round trip (16 of them at
+  // B=512: that, not the reduction, was this kernel's 16 us)
+  for (int i0 = tid; i0 < n_mse; i0 += 256 * 8) {
+    float4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + q * 256;
+      v[q] = i < n_mse ? reinterpret_cast<const float4*>(mse_part)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { s[0] += v[q].x; s[1] += v[q].y; s[2] += v[q].z; s[3] += v[q].w; }
   }
   for (int i = tid; i < n_ce; i += 256) { s[4] += ce_part[i * 2]; s[5] += ce_part[i * 2 + 1]; }
-  for (int k = 0; k < 6; ++k) red[tid][k] = s[k];
-  __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if (tid < o) for (int k = 0; k < 6; ++k) red[tid][k] += red[tid + o][k];
-    __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {       // (round 2: a 9-step LDS tree with 8 barriers over fp64[256][6], 16-18 us inside the step)
+    const double w = lf_wave_sum(s[k]);
+    if ((tid & 63) == 0) red[tid >> 6][k] = w;
   }
+  __syncthreads();
   if (tid == 0) {
-    float mse = (float)(red[0][0] * inv_numel);
-    float cem = n_ce ? (float)(red[0][4] / B) : 0.f;
+    double r[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    float mse = (float)(r[0] * inv_numel);
+    float cem = n_ce ? (float)(r[4] / B) : 0.f;
     float loss = alpha * mse + cem;
-    if (db4) { db4[0] = (float)red[0][1]; db4[1] = (float)red[0][2]; db4[2] = (float)red[0][3]; }
-    if (accum) { accum[0] += loss * B; accum[1] += mse * B; accum[2] += cem * B; accum[3] += B; accum[4] += (float)red[0][5]; }
+    if (db4) { db4[0] = (float)r[1]; db4[1] = (float)r[2]; db4[2] = (float)r[3]; }
+    if (accum) { accum[0] += loss * B; accum[1] += mse * B; accum[2] += cem * B; accum[3] += B; accum[4] += (float)r[5]; }
     if (last) { last[0] = loss; last[1] = mse; last[2] = cem; }
   }
 }
@@ -196,4 +283,3 @@ int eae_launch_ce_mean(hipStream_t st, const float* ce_part, int n, int B, float
   return 0;
 }
 
-int eae_head_blocks(int B) { return (B + HR - 1) / HR; }

@@ -60,22 +60,41 @@ struct ConvArgs {
     unsigned long long t__; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); a.dbg[64 + 2 * blockIdx.x + (k)] = t__; \
     if ((k) == 0) { unsigned id__; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id__)); unsigned xcc__; \
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc__)); a.dbg[64 + 2 * 8192 + blockIdx.x] = ((unsigned long long)xcc__ << 32) | id__; } } } while (0)
+// stamp by the first lane of an arbitrary wave (igemm2: consumer wave 0 = thread 0, producer wave 4 = thread 256)
+#define EAE_STAMP_T(i, t) do { if (a.dbg && (int)blockIdx.x == a.dbg_block && blockIdx.y == 0 && threadIdx.x == (t)) { \
+    unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); a.dbg[i] = t__; } } while (0)
 #else
 #define EAE_STAMP(i) do {} while (0)
 #define EAE_STAMP_WG(k) do {} while (0)
+#define EAE_STAMP_T(i, t) do {} while (0)
 #endif
 
 enum { KIND_CONV = 0, KIND_DECONV = 1 };
 constexpr int PIX_STRIDE = 40;       // edge / wgrad kernels: bf16 elements per staged pixel, 32 channels + 8 pad (80 B)
 // igemm patch: 2-D image [img][row][PWS pixels][32 ch], 64 B per pixel and no padding bytes (a 16x8 conv tile then fits
-// 4 workgroups per CU).  Inside every 256-byte group of 4 pixels of a row both the pixel slot and the 16-byte chunk are
-// XOR-ed with the group index, so the stride-2 fragment reads of the conv tiles are conflict-free (ds_read_b128 16-lane
-// groups {0-3,12-15,20-27},...; checked exhaustively per geometry, m-tile and tap: 16x8 and 8x8 conv 1.0-way, deconv 2-way as
-// with 80-byte padding).  Because the swizzle only depends on the column, a fragment address is
-//   (per-lane, per-kx base) + (compile-time row offset)  ->  the row part folds into the ds_read immediate offset.
-__device__ __forceinline__ int swz_col(int col, int kg) {     // element offset of (column, 8-channel group) inside a row
-  int r = col >> 2;
-  return ((col & ~3) | ((col ^ r) & 3)) * 32 + ((kg ^ r) & 3) * 8;
+// 4 workgroups per CU).  Inside every 256-byte group of 4 pixels of a row the pixel slot j and the 16-byte chunk c are permuted so
+// that the 16-lane groups of a ds_read_b128 fragment read ({0-3,12-15,20-27}, ...: 16 positions x 4 k-groups) hit 16 different
+// 16-byte bank slots.  Rows and images are multiples of 256 bytes apart, so which permutation works depends on how the 16
+// positions of an m-tile spread over columns and rows -- one per geometry class, found by exhaustive search and checked for
+// every (m-tile, tap) of every geometry by tools/lds_conflicts.py (4 LDS cycles per read = conflict-free everywhere; the
+// round-2 layout, class 0 for every geometry, cost 8 on the 4x4 conv tiles and on every transposed tile, 12-16 on the 4x4
+// transposed ones -- the deep layers were LDS-bound on those reads):
+//   class 0  conv, 16-wide tiles      : j ^ r, c ^ r                      (r = column / 4)
+//   class 1  conv, 8- / 4-wide tiles  : j ^ (row / 2), c ^ 2r             (an m-tile spans 2-4 rows; rows alias mod 256 B)
+//   class 2  transposed, 16-wide tiles: j, c ^ 2r
+//   class 3  transposed, 8- / 4-wide  : j, c ^ 2 row
+// Classes 0 and 2 depend on the column only: a fragment address is (per-lane, per-kx base) + (compile-time row offset), the row
+// part folds into the ds_read immediate.  Classes 1 and 3 depend on (lane row + compile-time row) mod 4 / mod 2: one lane base per
+// residue (frag_lane's `var`).
+template <int SWZ>
+__device__ __forceinline__ int swz_px(int col, int kg, int row) {     // element offset of (column, 8-channel group) inside a patch row
+  const int r = col >> 2, j = col & 3;
+  int jj, cc;
+  if (SWZ == 0) { jj = (j ^ r) & 3; cc = (kg ^ r) & 3; }
+  else if (SWZ == 1) { jj = (j ^ (row >> 1)) & 3; cc = (kg ^ (2 * r)) & 3; }
+  else if (SWZ == 2) { jj = j; cc = (kg ^ (2 * r)) & 3; }
+  else { jj = j; cc = (kg ^ (2 * row)) & 3; }
+  return ((col & ~3) | jj) * 32 + cc * 8;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -222,13 +241,24 @@ struct Geo {
   static constexpr int RPM = (16 / TW) ? (16 / TW) : 1;            // tile rows per 16-position m-tile
   static constexpr int NPH = (KIND == KIND_CONV) ? 1 : 4;          // output phases
   static constexpr int NOFF = (KIND == KIND_CONV) ? 9 : 4;         // distinct patch offsets
+#ifdef EAE_SWZ_OLD      // diagnostic builds: the round-2 layout for every geometry (tools/ab.py A/B)
+  static constexpr int SWZ = 0;
+#else
+  static constexpr int SWZ = (KIND == KIND_CONV) ? (TW == 16 ? 0 : 1) : (TW == 16 ? 2 : 3);       // swizzle class (swz_px)
+#endif
+  static constexpr int NVAR = (SWZ == 1) ? 4 : (SWZ == 3) ? 2 : 1;                                   // lane bases per column offset
+  __device__ static __forceinline__ int swz(int col, int kg, int row) { return swz_px<SWZ>(col, kg, row); }
+  // residue class of a compile-time row offset `radd` (patch rows added to the lane's own row MUL * ty)
+  __device__ static constexpr int var_of(int radd) { return (SWZ == 1) ? ((radd >> 1) & 3) : (SWZ == 3) ? (radd & 1) : 0; }
   // patch pixel of position m for offset 0
-  // per-lane part: i = lane & 15 (position inside the m-tile), wbase = index of the wave's first m-tile, column offset kx
-  __device__ static __forceinline__ int frag_lane(int i, int wbase, int kx, int kg) {
+  // per-lane part: i = lane & 15 (position inside the m-tile), wbase = index of the wave's first m-tile, column offset kx,
+  // var = residue class of the compile-time row offset the base will be used with (var_of)
+  __device__ static __forceinline__ int frag_lane(int i, int wbase, int kx, int kg, int var = 0) {
     int img, ty, tx = i % TW;
     if (TH * TW <= 16) { img = wbase; ty = i / TW; }
     else { int row = wbase * RPM + i / TW; img = row / TH; ty = row % TH; }
-    return (img * PH + MUL * ty) * RS + swz_col(MUL * tx + kx, kg);
+    const int srow = (SWZ == 1) ? MUL * ty + 2 * var : MUL * ty + var;      // any row with the same residue as (lane row + offset)
+    return (img * PH + MUL * ty) * RS + swz(MUL * tx + kx, kg, srow);
   }
   // tap (ky,kx) -> patch offset id / phase.  deconv: oy = 2*iy - 1 + ky  =>  ky=1: (py=0, dy=0); ky=2: (py=1, dy=0); ky=0: (py=1, dy=1)
   __device__ static constexpr int tap_off(int tap) {
@@ -243,6 +273,10 @@ struct Geo {
   __device__ static constexpr int frag_const(int mi, int o) {
     return (TH * TW <= 16) ? (mi * PH + off_row(o)) * RS
                            : (((mi * RPM) / TH) * PH + MUL * ((mi * RPM) % TH) + off_row(o)) * RS;
+  }
+  // patch rows (inside the image) that frag_const adds to the lane's own row: selects the lane base (var_of)
+  __device__ static constexpr int frag_radd(int mi, int o) {
+    return (TH * TW <= 16) ? off_row(o) : MUL * ((mi * RPM) % TH) + off_row(o);
   }
 };
 
@@ -323,7 +357,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   {
     const int bid = blockIdx.x;
     if (NB == 1) { tile_id = bid; nblk = 0; }
-    else if (a.ntiles % 8 == 0) { const int xcd = bid & 7, idx = bid >> 3; nblk = idx % NB; tile_id = (idx / NB) * 8 + xcd; }
+    else if ((a.ntiles * NB) % 8 == 0) { const int li = (bid & 7) * ((a.ntiles * NB) >> 3) + (bid >> 3); nblk = li % NB; tile_id = li / NB; }   // contiguous run of (tile, block) pairs per XCD
     else { nblk = bid % NB; tile_id = bid / NB; }
   }
   int t = tile_id;
@@ -344,9 +378,11 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
 
   const int kgl = lane >> 4;        // k-group of the lane inside an MFMA (8 channels)
   static_assert(TH * TW <= 16 || (TH % (MT * G::RPM) == 0) || (WM == 1 && (MT * G::RPM) % TH == 0), "m-tile rows must not straddle images");
-  int lbase[G::NKX];                // swizzled fragment base of this lane per column offset; rows are immediate offsets
+  int lbase[G::NKX][G::NVAR];       // swizzled fragment base of this lane per column offset (and row residue); rows are immediate offsets
 #pragma unroll
-  for (int kx = 0; kx < G::NKX; ++kx) lbase[kx] = G::frag_lane(lane & 15, wm * MT, kx, kgl);
+  for (int kx = 0; kx < G::NKX; ++kx)
+#pragma unroll
+    for (int v = 0; v < G::NVAR; ++v) lbase[kx][v] = G::frag_lane(lane & 15, wm * MT, kx, kgl, v);
   const int kgs = tid & 3;          // k-group staged by this thread (256 % 4 == 0 -> fixed per thread)
   // this lane's weight-fragment row: output channel n0 + wn*16 + (lane&15), 8 input channels kgl*8..
   const bf16_t* wrow = a.wpack + (size_t)(n0 + wn * 16 + (lane & 15)) * 9 * CIN + kgl * 8;
@@ -371,7 +407,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
       int iy = iy0 + pr, ix = ix0 + pc, n = img0 + img;
       val[i] = (tid + i * 256 < NPIX * 4) && (n < a.B) && ((unsigned)iy < (unsigned)a.Hin) && ((unsigned)ix < (unsigned)a.Win);
       boff[i] = val[i] ? ((uint32_t)((n * a.Hin + iy) * a.Win + ix) * CIN + kgs * 8) * 2u : OOB_OFF;
-      loff[i] = (img * PH + pr) * G::RS + swz_col(pc, kgs);
+      loff[i] = (img * PH + pr) * G::RS + G::swz(pc, kgs, pr);
       pc += DC; pr += DR; img += DI;
       if (pc >= PW) { pc -= PW; pr += 1; }
       if (pr >= PH) { pr -= PH; img += 1; }
@@ -461,12 +497,12 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
       constexpr int NROWS = G::MUL * MT + 1;
       bf16x8 rf[2][G::NKX];
 #pragma unroll
-      for (int kx = 0; kx < G::NKX; ++kx) rf[0][kx] = *reinterpret_cast<const bf16x8*>(patch + lbase[kx]);
+      for (int kx = 0; kx < G::NKX; ++kx) rf[0][kx] = *reinterpret_cast<const bf16x8*>(patch + lbase[kx][0]);
 #pragma unroll
       for (int R = 0; R < NROWS; ++R) {
         if (R + 1 < NROWS) {
 #pragma unroll
-          for (int kx = 0; kx < G::NKX; ++kx) rf[(R + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(patch + lbase[kx] + (R + 1) * G::RS);
+          for (int kx = 0; kx < G::NKX; ++kx) rf[(R + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(patch + lbase[kx][0] + (R + 1) * G::RS);
         }
         // pin the order "fragments of row R+1 requested, then the MFMAs of row R": left alone, hipcc sinks the ds_read_b128 next to
         // their MFMAs (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma: a full LDS round trip per MFMA, seen in the ISA of several instances)
@@ -494,13 +530,13 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
     bf16x8 pf[PFB][MT];
   #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
-        pf[0][mi] = *reinterpret_cast<const bf16x8*>(patch + lbase[G::off_col(0)] + G::frag_const(mi, 0));
+        pf[0][mi] = *reinterpret_cast<const bf16x8*>(patch + lbase[G::off_col(0)][G::var_of(G::frag_radd(mi, 0))] + G::frag_const(mi, 0));
   #pragma unroll
       for (int o = 0; o < G::NOFF; ++o) {
         if (PFB == 2 && o + 1 < G::NOFF) {
   #pragma unroll
           for (int mi = 0; mi < MT; ++mi)
-            pf[(o + 1) % PFB][mi] = *reinterpret_cast<const bf16x8*>(patch + lbase[G::off_col(o + 1)] + G::frag_const(mi, o + 1));
+            pf[(o + 1) % PFB][mi] = *reinterpret_cast<const bf16x8*>(patch + lbase[G::off_col(o + 1)][G::var_of(G::frag_radd(mi, o + 1))] + G::frag_const(mi, o + 1));
         }
         if (PFB == 2) __builtin_amdgcn_sched_barrier(0);      // fragments of offset o+1 requested BEFORE the MFMAs of offset o (see above)
   #pragma unroll
@@ -513,7 +549,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
         if (PFB == 1 && o + 1 < G::NOFF) {
   #pragma unroll
           for (int mi = 0; mi < MT; ++mi)
-            pf[0][mi] = *reinterpret_cast<const bf16x8*>(patch + lbase[G::off_col(o + 1)] + G::frag_const(mi, o + 1));
+            pf[0][mi] = *reinterpret_cast<const bf16x8*>(patch + lbase[G::off_col(o + 1)][G::var_of(G::frag_radd(mi, o + 1))] + G::frag_const(mi, o + 1));
         }
         if (chunk + 1 < NC) issue_slice(chunk + 1, o);
       }

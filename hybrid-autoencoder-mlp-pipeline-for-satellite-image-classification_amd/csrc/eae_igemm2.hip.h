@@ -55,7 +55,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {
     const int bid = blockIdx.x;
     if (NB == 1 || NBL > 1) { tile_id = bid; nblk = 0; }
-    else if (a.ntiles % 8 == 0) { const int xcd = bid & 7, idx = bid >> 3; nblk = idx % NB; tile_id = (idx / NB) * 8 + xcd; }
+    else if ((a.ntiles * NB) % 8 == 0) { const int li = (bid & 7) * ((a.ntiles * NB) >> 3) + (bid >> 3); nblk = li % NB; tile_id = li / NB; }   // contiguous run of (tile, block) pairs per XCD
     else { nblk = bid % NB; tile_id = bid / NB; }
   }
   int t = tile_id;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int iy = iy0 + pr, ix = ix0 + pc, n = img0 + img;
         val[i] = (ptid + i * 256 < NPIX * 4) && (n < a.B) && ((unsigned)iy < (unsigned)a.Hin) && ((unsigned)ix < (unsigned)a.Win);
         boff[i] = val[i] ? ((uint32_t)((n * a.Hin + iy) * a.Win + ix) * CIN + kgs * 8) * 2u : OOB_OFF;
-        loff[i] = (img * PH + pr) * G::RS + swz_col(pc, kgs);
+        loff[i] = (img * PH + pr) * G::RS + G::swz(pc, kgs, pr);
         pc += DC; pr += DR; img += DI;
         if (pc >= PW) { pc -= PW; pr += 1; }
         if (pr >= PH) { pr -= PH; img += 1; }
@@ -111,8 +111,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     BnFoldRegsB frb;
     if (folded) bn_fold_load<CIN>(a.fold, fr, ptid);      // accumulator loads first: vector-memory results return in issue order
     if (folded_b) bn_fold_bwd_load<CIN>(a.bfold, frb, ptid);
+    EAE_STAMP_T(100, 256);
     issue(0, ra);
     issue(1, rb);
+    EAE_STAMP_T(101, 256);
     if (folded) {
       bn_fold_fwd_finish<CIN>(a.fold, fr, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0, ptid);   // two barriers
       coefp = coef_tab;
@@ -121,16 +123,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       bn_fold_bwd_finish<CIN>(a.bfold, frb, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0, ptid);  // two barriers
       coefp = coef_tab;
     }
+    EAE_STAMP_T(102, 256);
     stage(0, ra, patch0);
     if (NC > 2) issue(2, ra);
+    EAE_STAMP_T(103, 256);
     __syncthreads();                                       // chunk 0 staged
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
+      EAE_STAMP_T(104 + 3 * c, 256);
       if (c + 1 < NC) {
         stage(c + 1, ((c + 1) & 1) ? rb : ra, ((c + 1) & 1) ? patch1 : patch0);
         if (c + 3 < NC) issue(c + 3, ((c + 1) & 1) ? rb : ra);
       }
+      EAE_STAMP_T(105 + 3 * c, 256);
       __syncthreads();                                     // chunk c multiplied, chunk c+1 staged
+      EAE_STAMP_T(106 + 3 * c, 256);
     }
     return;                                                // the epilogue is the consumers' (s_barrier only counts live waves)
   }
@@ -138,9 +145,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ================================================================== consumers
   const int wn = wave % WN, wm = wave / WN;
   const int kgl = lane >> 4;        // k-group of the lane inside an MFMA (8 channels)
-  int lbase[G::NKX];                // swizzled fragment base of this lane per column offset; rows are immediate offsets
+  int lbase[G::NKX][G::NVAR];       // swizzled fragment base of this lane per column offset (and row residue); rows are immediate offsets
 #pragma unroll
-  for (int kx = 0; kx < G::NKX; ++kx) lbase[kx] = G::frag_lane(lane & 15, wm * MT, kx, kgl);
+  for (int kx = 0; kx < G::NKX; ++kx)
+#pragma unroll
+    for (int v = 0; v < G::NVAR; ++v) lbase[kx][v] = G::frag_lane(lane & 15, wm * MT, kx, kgl, v);
   f32x4 acc[NPH][MT];
   bf16x8 wfa[9], wfb[9];
   const bf16_t* wrow = nullptr;
@@ -157,12 +166,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       constexpr int NROWS = G::MUL * MT + 1;
       bf16x8 rf[2][G::NKX];
 #pragma unroll
-      for (int kx = 0; kx < G::NKX; ++kx) rf[0][kx] = *reinterpret_cast<const bf16x8*>(patch + lbase[kx]);
+      for (int kx = 0; kx < G::NKX; ++kx) rf[0][kx] = *reinterpret_cast<const bf16x8*>(patch + lbase[kx][0]);
 #pragma unroll
       for (int R = 0; R < NROWS; ++R) {
         if (R + 1 < NROWS) {
 #pragma unroll
-          for (int kx = 0; kx < G::NKX; ++kx) rf[(R + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(patch + lbase[kx] + (R + 1) * G::RS);
+          for (int kx = 0; kx < G::NKX; ++kx) rf[(R + 1) & 1][kx] = *reinterpret_cast<const bf16x8*>(patch + lbase[kx][0] + (R + 1) * G::RS);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -181,13 +190,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       bf16x8 pf[2][MT];
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
-        pf[0][mi] = *reinterpret_cast<const bf16x8*>(patch + lbase[G::off_col(0)] + G::frag_const(mi, 0));
+        pf[0][mi] = *reinterpret_cast<const bf16x8*>(patch + lbase[G::off_col(0)][G::var_of(G::frag_radd(mi, 0))] + G::frag_const(mi, 0));
 #pragma unroll
       for (int o = 0; o < G::NOFF; ++o) {
         if (o + 1 < G::NOFF) {
 #pragma unroll
           for (int mi = 0; mi < MT; ++mi)
-            pf[(o + 1) & 1][mi] = *reinterpret_cast<const bf16x8*>(patch + lbase[G::off_col(o + 1)] + G::frag_const(mi, o + 1));
+            pf[(o + 1) & 1][mi] = *reinterpret_cast<const bf16x8*>(patch + lbase[G::off_col(o + 1)][G::var_of(G::frag_radd(mi, o + 1))] + G::frag_const(mi, o + 1));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -218,17 +227,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // this lane's weight-fragment row: output channel n0 + wn*16 + (lane&15), 8 input channels kgl*8..
     wrow = a.wpack + (size_t)(n0 + wn * 16 + (lane & 15)) * 9 * CIN + kgl * 8;
+    EAE_STAMP_T(0, 0);
     load_w(0, wfa);
     load_w(1, wfb);
     if (nbi == 0) {
       if (folded || folded_b) { __syncthreads(); __syncthreads(); }    // the producers' coefficient-table barriers
       __syncthreads();                                     // chunk 0 staged
     }
+    EAE_STAMP_T(1, 0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
+      EAE_STAMP_T(8 + 3 * c, 0);
       mfma_chunk((c & 1) ? patch1 : patch0, (c & 1) ? wfb : wfa);
       if (c + 2 < NC) load_w(c + 2, (c & 1) ? wfb : wfa);
+      EAE_STAMP_T(9 + 3 * c, 0);
       if (nbi == 0) __syncthreads();                       // chunk c multiplied, chunk c+1 staged (the producers retire after the last one)
+      EAE_STAMP_T(10 + 3 * c, 0);
     }
     // ---- epilogue (the one-role kernel's): per phase, accumulators -> LDS tile -> global
     constexpr int PHG = (KIND == KIND_CONV) ? 1 : 2, R2 = P * PHG;
@@ -288,5 +302,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
     epi.end(a, red, n0, tile_id);
+    EAE_STAMP_T(2, 0);
   }
 }

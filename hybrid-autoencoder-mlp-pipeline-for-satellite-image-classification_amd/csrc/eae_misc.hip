@@ -163,17 +163,24 @@ int eae_launch_bn_bwd_finalize(hipStream_t st, const float* part, int ntiles, in
 // Device-side stream dependencies.  gate_kernel: one lane polls up to 4 progress words (relaxed agent-scope loads, s_sleep
 // between polls) until each has reached its value; the kernels behind it on the same stream then see everything the signalling
 // stream had completed when it published the value (kernel-boundary acquire).  Values only grow (wrap-safe signed compare).
-// The spin is bounded: after ~2 s the gate gives up and records the value it was waiting for in `timeout` (the step's
-// results are then wrong; eae_gate_timeouts() reports it).  signal_kernel publishes a value from a stream that has no
-// other kernel to carry it.
+// The spin is bounded by WALL-CLOCK time (s_memrealtime, 100 MHz; default 30 s, EAE_GATE_TIMEOUT_MS): a caller's stream that is
+// stalled for seconds in front of the step (a late data-parallel peer inside the previous step's all-reduce, a long copy) is waited
+// for.  A gate that does give up records the value it was waiting for in the STICKY word `timeout`: the work behind it then ran too
+// early, so every later optimizer kernel of the context refuses to update the parameters and writes NaN losses
+// (adam_kernel `bad`), the steppers raise (eae_gate_timeouts()).  signal_kernel publishes a value from a stream that has no other
+// kernel to carry it.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ EAE_NO_PK __launch_bounds__(64) void gate_kernel(GateArgs g) {
   if (threadIdx.x != 0) return;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (int k = 0; k < g.n; ++k) {
     unsigned spins = 0;
     while ((int)(__hip_atomic_load(g.word[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.want[k]) < 0) {
       __builtin_amdgcn_s_sleep(16);
-      if (++spins > (1u << 22)) { atomicExch(g.timeout, g.want[k] ? g.want[k] : 1u); return; }
+      if ((++spins & 255u) == 0 && g.limit_ticks != 0 && __builtin_amdgcn_s_memrealtime() - t0 > g.limit_ticks) {
+        atomicExch(g.timeout, g.want[k] ? g.want[k] : 1u);
+        return;
+      }
     }
   }
 }
@@ -409,9 +416,16 @@ void eae_fp8_state_init(Fp8State* h) {
 // ---------------------------------------------------------------------------------------------------------------
 __global__ EAE_NO_PK __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n4, float b1, float b2, float step_size,
-                                                    float bc2_sqrt, float eps, float wd, float gscale, uint4* __restrict__ zbuf, long zn16) {
+                                                    float bc2_sqrt, float eps, float wd, float gscale, uint4* __restrict__ zbuf, long zn16,
+                                                    const unsigned* __restrict__ bad, float* __restrict__ nan_out) {
   // side job: clear the BatchNorm statistics accumulators for the next step (every consumer of this step has finished)
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zn16; i += (long)gridDim.x * 256) zbuf[i] = make_uint4(0, 0, 0, 0);
+  // a side-stream gate of this context has timed out at some point (sticky word): gradients may have been computed from stale
+  // activations -- no update, and the step's loss scalars become NaN so that the run cannot go on unnoticed
+  if (bad != nullptr && __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    if (nan_out != nullptr && blockIdx.x == 0 && threadIdx.x < 3) nan_out[threadIdx.x] = __builtin_nanf("");
+    return;
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
     float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -436,7 +450,12 @@ __global__ EAE_NO_PK __launch_bounds__(256) void adam_kernel(float* __restrict__
 // so that a captured hipGraph of the whole train step can be replayed while the step count advances.
 __global__ EAE_NO_PK __launch_bounds__(256) void adam_dyn_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n4, float b1, float b2, float eps,
-                                                        const float* __restrict__ dyn) {
+                                                        const float* __restrict__ dyn, const unsigned* __restrict__ bad,
+                                                        float* __restrict__ nan_out) {
+  if (bad != nullptr && __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {     // see adam_kernel
+    if (nan_out != nullptr && blockIdx.x == 0 && threadIdx.x < 3) nan_out[threadIdx.x] = __builtin_nanf("");
+    return;
+  }
   const float step_size = dyn[0], bc2_sqrt = dyn[1], wd = dyn[2];
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -460,12 +479,12 @@ __global__ EAE_NO_PK __launch_bounds__(256) void adam_dyn_kernel(float* __restri
 __global__ EAE_NO_PK void set_dyn_kernel(float* dyn, float a, float b, float c) { dyn[0] = a; dyn[1] = b; dyn[2] = c; }
 
 int eae_launch_adam_dyn(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double b1, double b2, double eps,
-                        const float* dyn) {
+                        const float* dyn, const unsigned* bad, float* nan_out) {
   if (n % 4) return eae_set_error(-2, "adam: arena length must be a multiple of 4");
   long n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adam_dyn_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4, (float)b1, (float)b2, (float)eps, dyn);
+  hipLaunchKernelGGL(adam_dyn_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4, (float)b1, (float)b2, (float)eps, dyn, bad, nan_out);
   EAE_LAUNCH_CHECK();
   return 0;
 }
@@ -482,14 +501,15 @@ int eae_launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v
 }
 
 int eae_launch_adam_scaled(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
-                           double eps, double wd, long long step, float gscale, void* zero_buf, long long zero_bytes) {
+                           double eps, double wd, long long step, float gscale, void* zero_buf, long long zero_bytes,
+                           const unsigned* bad, float* nan_out) {
   if (n % 4) return eae_set_error(-2, "adam: arena length must be a multiple of 4");
   double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
   long n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4, (float)b1, (float)b2, (float)(lr / bc1),
-                     (float)sqrt(bc2), (float)eps, (float)wd, gscale, (uint4*)zero_buf, (long)(zero_bytes / 16));
+                     (float)sqrt(bc2), (float)eps, (float)wd, gscale, (uint4*)zero_buf, (long)(zero_bytes / 16), bad, nan_out);
   EAE_LAUNCH_CHECK();
   return 0;
 }

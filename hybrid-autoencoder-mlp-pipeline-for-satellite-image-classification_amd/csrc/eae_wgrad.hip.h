@@ -82,8 +82,15 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   int slice, oblk;
   {
     const int bid = blockIdx.x;
+    const int total = a.nslices * NBLK;
     if (NBLK == 1) { slice = bid; oblk = 0; }
-    else if (a.nslices % 8 == 0) { const int xcd = bid & 7, idx = bid >> 3; oblk = idx % NBLK; slice = (idx / NBLK) * 8 + xcd; }
+    else if (total % 8 == 0) {
+      // every XCD takes a CONTIGUOUS run of (slice, block) pairs: the blocks of a slice land on as few XCDs as possible (one when
+      // nslices % 8 == 0; two at 4 slices x 16 blocks, where the round-1 fallback `bid % NBLK` spread a slice's blocks over all eight
+      // and every operand tile was fetched 4.25x: profiles/r02_per_kernel_roofline.md)
+      const int li = (bid & 7) * (total >> 3) + (bid >> 3);
+      slice = li / NBLK; oblk = li % NBLK;
+    }
     else { oblk = bid % NBLK; slice = bid / NBLK; }
   }
   const int cs0 = (oblk / (CB / 32)) * 64, cb0 = (oblk % (CB / 32)) * 32;
@@ -285,9 +292,15 @@ __device__ __forceinline__ void reduce_slices_body(const float* __restrict__ par
   const long i = (long)blockIdx.x * 16 + lx;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n4)
-    for (int sidx = ly; sidx < nslices; sidx += 16) {
-      float4 v = reinterpret_cast<const float4*>(part)[(long)sidx * n4 + i];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    for (int s0 = ly; s0 < nslices; s0 += 16 * 4) {     // 4 loads in flight, summed in slice order (one load per iteration exposed a
+      float4 v[4];                                       // memory round trip per slice: these kernels were ~6 us of pure latency)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int sidx = s0 + 16 * q;
+        v[q] = sidx < nslices ? reinterpret_cast<const float4*>(part)[(long)sidx * n4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { s.x += v[q].x; s.y += v[q].y; s.z += v[q].z; s.w += v[q].w; }
     }
   red[ly][lx] = s;
   __syncthreads();
@@ -319,9 +332,15 @@ static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_tall_kerne
   const long i = (long)blockIdx.x * 4 + lx;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n4)
-    for (int sidx = ly; sidx < nslices; sidx += 64) {
-      float4 v = reinterpret_cast<const float4*>(part)[(long)sidx * n4 + i];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    for (int s0 = ly; s0 < nslices; s0 += 64 * 8) {     // 8 loads in flight, summed in slice order
+      float4 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int sidx = s0 + 64 * q;
+        v[q] = sidx < nslices ? reinterpret_cast<const float4*>(part)[(long)sidx * n4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { s.x += v[q].x; s.y += v[q].y; s.z += v[q].z; s.w += v[q].w; }
     }
   red[ly][lx] = s;
   __syncthreads();

@@ -107,6 +107,17 @@ class DataParallelTrainer:
         been launched, so RCCL moves it over xGMI while the encoder half is still computing; the encoder-side bucket follows
         after the second half.  The 1/world scaling is folded into the Adam kernel."""
         eng = self.eng
+        if self.sync_bn is not None:
+            # SyncBN multiplies the per-rank element count by the world size (eae_api.hip fold_consumer / bn_bwd_fin): every rank must
+            # feed the same number of images, or mean / variance / the backward terms are silently wrong (ADVICE r2).  One tiny
+            # collective more in a mode that already issues 14 per step.
+            b = int(x.shape[0])
+            t = torch.tensor([b, -b], dtype=torch.int64, device=x.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+            hi, lo = int(t[0]), -int(t[1])
+            if hi != lo:
+                raise RuntimeError(f"SyncBatchNorm needs the same per-rank batch size on every rank (this step: {lo}..{hi}); pad or drop "
+                                   "the short last batch (sampler with drop_last / padding), or train without sync_bn")
         side = eng.side_stream() if hasattr(eng, "grad_step_begin") and hasattr(eng, "side_stream") else None
         if side is None:                       # engines without the split API (CPU stand-in of the gloo test)
             eng.grad_step(x, labels, alpha, head=head)
@@ -186,6 +197,8 @@ class DPAEStepper:
         acc = self.eng.loss_accum.clone()
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.pg)
         a = acc.tolist()
+        if hasattr(self.eng, "check_gates"):
+            self.eng.check_gates()      # the .tolist() above has synchronised; a timed-out side-stream gate must not go unnoticed
         n = max(a[3], 1.0)
         return a[0] / n, int(a[3])
 

@@ -19,6 +19,7 @@ from . import _lib
 from ._lib import EaeConfig, EaeStepIO, check
 
 _ENGINES = weakref.WeakKeyDictionary()
+_ENGINES_LOCK = __import__("threading").RLock()     # engine_for() may be called from the worker threads of the concurrent grid driver
 
 
 def _ptr(t):
@@ -165,6 +166,24 @@ class AEEngine:
         """0, or the progress value a side-stream gate gave up waiting for (diagnostic; synchronises the device)."""
         with torch.cuda.device(self.device):
             return int(self.lib.eae_gate_timeouts(self.ctx))
+
+    def check_gates(self, sync=True):
+        """Raise if a side-stream gate of this engine has ever timed out (sticky; the optimizer kernels have refused to update since,
+        and the loss scalars of those steps are NaN).  sync=True synchronises the device; sync=False only reads the word (for callers
+        that have just synchronised the stream they step on, e.g. after read_loss(): the concurrent grid driver)."""
+        if sync:
+            v = self.gate_timeouts()
+        else:
+            with torch.cuda.device(self.device):
+                v = int(self.lib.eae_gate_timeouts_nosync(self.ctx))
+        if v:
+            raise _lib.EaeError(f"a side-stream gate timed out waiting for progress value {v}: weight gradients of that step may come "
+                                "from stale activations; no parameter update has been applied since (raise EAE_GATE_TIMEOUT_MS, or "
+                                "EAE_FORK_EVENTS=1 for event hand-overs; clear with engine.clear_gate_timeouts())")
+
+    def clear_gate_timeouts(self):
+        with torch.cuda.device(self.device):
+            check(self.lib.eae_gate_timeouts_clear(self.ctx))
 
     def generation(self):
         """Id of the most recent forward (eae_ae_backward only differentiates the resident one)."""
@@ -329,6 +348,11 @@ def engine_for(module, max_batch=None, quant=None):
     """Engine of the SupervisedAutoencoder that owns `module` (or of a stand-alone Encoder / Decoder).  quant="fp8": BASELINE config
     5's variant (fp8 operands for the GEMMs of the six 3x3 layers, include/eae.h); it is a property of the engine, chosen when the
     engine of a module is first built (`module._eae_quant = "fp8"` before the first use does the same)."""
+    with _ENGINES_LOCK:
+        return _engine_for_locked(module, max_batch, quant)
+
+
+def _engine_for_locked(module, max_batch, quant):
     root = _root_of(module)
     eng = _ENGINES.get(root)
     quant = quant if quant is not None else getattr(root, "_eae_quant", None)
@@ -401,6 +425,8 @@ class _HalfFunction(torch.autograd.Function):
         inp = inp.contiguous()
         out = eng.encoder(inp, train=train) if half == "enc" else eng.decoder(inp, train=train)
         ctx.eng, ctx.half, ctx.gen = eng, half, eng.generation()
+        if half == "enc":
+            eng._pending_enc_gen = ctx.gen       # an encoder forward that still awaits its backward is resident in this engine
         ctx.save_for_backward(inp, out)
         ctx.slots = [(p, i) for p, i in eng._slots if (i < 18 if half == "enc" else 18 <= i < 34)]
         ctx.need = [p.requires_grad for p in params]
@@ -416,6 +442,7 @@ class _HalfFunction(torch.autograd.Function):
         with torch.cuda.device(eng.device):
             if ctx.half == "enc":
                 check(eng.lib.eae_encoder_backward(eng.ctx, _stream(), ctx.gen, _ptr(inp), _ptr(dout)))     # (no dL/dx: images are leaves)
+                eng._pending_enc_gen = None
             else:
                 din = torch.empty_like(inp) if ctx.need_input else None
                 check(eng.lib.eae_decoder_backward(eng.ctx, _stream(), ctx.gen, _ptr(out), _ptr(dout), _ptr(din)))
@@ -428,7 +455,19 @@ def _half_forward(module, inp, half):
     eng = engine_for(module)
     eng.params_changed()
     slots = [p for p, i in eng._slots if (i < 18 if half == "enc" else 18 <= i < 34)]
-    if torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in slots)):
+    grad_mode = torch.is_grad_enabled()
+    if grad_mode and half == "enc" and inp.requires_grad:
+        # the engine computes no gradient w.r.t. the images (conv1 has no backward-data: the reference's inputs are leaves, R.md:643-647);
+        # silently returning None would starve a differentiable stage in front of the encoder
+        raise RuntimeError("Encoder.forward: the input requires grad, but the HIP engine does not compute dL/dx (images are leaves of the "
+                           "reference's graph); detach the input, or keep learnable pre-processing outside the differentiated path")
+    if grad_mode and half == "dec" and getattr(eng, "_pending_enc_gen", None) == eng.generation():
+        # model.dec(model.enc(x)) on the two halves of ONE SupervisedAutoencoder: both halves share one engine workspace and the
+        # decoder forward would replace the resident encoder forward that still awaits its backward
+        raise RuntimeError("Decoder.forward on the decoder of the SupervisedAutoencoder whose encoder forward is awaiting its backward: the "
+                           "two halves share one engine; call model(x) (x_hat, logits, z = model(x)), or use stand-alone Encoder / Decoder "
+                           "modules for a hand-composed dec(enc(x))")
+    if grad_mode and (inp.requires_grad or any(p.requires_grad for p in slots)):
         return _HalfFunction.apply(eng, half, bool(module.training), inp, *slots)
     return eng.encoder(inp, train=module.training) if half == "enc" else eng.decoder(inp, train=module.training)
 

@@ -38,6 +38,7 @@ class AEStepper:
 
     def end(self):
         loss, _, _, n, _ = self.eng.read_loss()
+        self.eng.check_gates(sync=False)   # (read_loss has synchronised this stream) a timed-out side-stream gate must not go unnoticed
         return loss, n
 
 
@@ -121,26 +122,80 @@ def fit_autoencoder(train_loader, val_loader, alpha, lr, latent_dim=64, num_clas
             "epochs": len(train_curve)}
 
 
+def run_concurrent(jobs, concurrent, device="cuda"):
+    """Run `jobs` (callables without arguments) on `concurrent` host threads, each with its OWN HIP stream current
+    (torch.cuda.stream is thread-local), and return their results in job order.  This is how several small configurations share one
+    GPU: at the reference's batch size 64 one train step is ~70 dependent launches of a few microseconds each, so a
+    single stream leaves most of the 256 CUs idle and a single host thread cannot enqueue faster than the GPU drains; K engine contexts
+    (own workspace, own side streams) stepped from K threads -- ctypes releases the GIL inside every libeae call -- overlap both."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    dev = torch.device(device)
+    if dev.type == "cuda" and not torch.cuda.is_available():
+        dev = None
+    tls = threading.local()
+
+    def run(job):
+        if dev is None or dev.type != "cuda":
+            return job()
+        if not hasattr(tls, "stream"):
+            tls.stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.device(dev), torch.cuda.stream(tls.stream):
+            out = job()
+            tls.stream.synchronize()
+        return out
+
+    with ThreadPoolExecutor(max_workers=max(1, int(concurrent))) as ex:
+        return list(ex.map(run, jobs))
+
+
 def grid_search_autoencoder(train_loader, val_loader, alpha_values=(20, 25, 30, 35, 40),
                             lr_values=(1e-4, 2e-4, 5e-4, 1e-3, 2e-3, 5e-3, 1e-2, 5e-2, 1e-1), latent_dim=64, num_epochs=80,
-                            patience=15, out_dir="models_best", device="cuda", verbose=True, log=print, fit_fn=None):
+                            patience=15, out_dir="models_best", device="cuda", verbose=True, log=print, fit_fn=None, concurrent=1):
     """The reference's alpha x lr grid (R.md:599-729): trains every configuration, keeps the global best, writes
-    `out_dir/AE_GLOBAL_BEST.pt` (plain state_dict) and `out_dir/validation_losses.json` (keys "alpha={a}, lr={lr}")."""
+    `out_dir/AE_GLOBAL_BEST.pt` (plain state_dict) and `out_dir/validation_losses.json` (keys "alpha={a}, lr={lr}").
+
+    concurrent=K > 1 trains K configurations at a time on the one GPU (run_concurrent): every configuration is an independent
+    engine context on its own stream, so its curves and final weights are bitwise those of the same configuration trained alone
+    (tests/test_gpu_grid.py); the log lines of a configuration are emitted together, in grid order, and the global best is chosen
+    in grid order with the reference's strict `<` -- the same winner as the sequential loop."""
     os.makedirs(out_dir, exist_ok=True)
     fit_fn = fit_fn or fit_autoencoder
     results, best = {}, {"loss": float("inf"), "info": None, "state": None, "train": None, "val": None}
-    for alpha in alpha_values:
-        for lr in lr_values:
+    grid = [(alpha, lr) for alpha in alpha_values for lr in lr_values]
+    fitted = None
+    if concurrent and int(concurrent) > 1:
+        def job_of(alpha, lr):
+            def job():
+                lines = []
+                r = fit_fn(train_loader, val_loader, alpha, lr, latent_dim=latent_dim, num_epochs=num_epochs, patience=patience,
+                           device=device, verbose=verbose, log=lines.append)
+                r = dict(r)
+                # only the state_dict of a finished configuration is needed below: release its engine (workspace, streams) now
+                r["state"] = None if r.get("model") is None else {k: v.detach().cpu().clone() for k, v in r["model"].state_dict().items()}
+                r["model"] = None
+                return r, lines
+            return job
+        fitted = run_concurrent([job_of(a, l) for a, l in grid], int(concurrent), device)
+    for gi, (alpha, lr) in enumerate(grid):
             if verbose:
                 log("\n=====================================")
                 log(f"Training AE for α={alpha}, LR={lr}")
                 log("=====================================")
-            r = fit_fn(train_loader, val_loader, alpha, lr, latent_dim=latent_dim, num_epochs=num_epochs, patience=patience,
-                       device=device, verbose=verbose, log=log)
+            if fitted is not None:
+                r, lines = fitted[gi]
+                if verbose:
+                    for ln in lines:
+                        log(ln)
+            else:
+                r = fit_fn(train_loader, val_loader, alpha, lr, latent_dim=latent_dim, num_epochs=num_epochs, patience=patience,
+                           device=device, verbose=verbose, log=log)
             results[(alpha, lr)] = r["best_val_loss"]
             if r["best_val_loss"] < best["loss"]:
-                best.update(loss=r["best_val_loss"], info=(alpha, lr), train=r["train_curve"], val=r["val_curve"],
-                            state=None if r["model"] is None else {k: v.detach().cpu().clone() for k, v in r["model"].state_dict().items()})
+                state = r.get("state")
+                if state is None and r.get("model") is not None:
+                    state = {k: v.detach().cpu().clone() for k, v in r["model"].state_dict().items()}
+                best.update(loss=r["best_val_loss"], info=(alpha, lr), train=r["train_curve"], val=r["val_curve"], state=state)
                 if verbose:
                     log("\nNew best AE")
                     log(f"   α={alpha}, LR={lr}, ValLoss={r['best_val_loss']:.4f}")

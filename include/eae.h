@@ -69,9 +69,16 @@ int eae_destroy(eae_ctx* ctx);
 int eae_bind(eae_ctx* ctx, float* params, float* grads, float* adam_m, float* adam_v, float* bn_running,
              long long* bn_nbt);
 /* The engine orders its side streams behind the caller's stream with one-wave GATE kernels that poll a device progress word
- * (no event record on the caller's stream; EAE_FORK_EVENTS=1 restores events).  Their spin is bounded (~2 s): this diagnostic
- * synchronises the device and returns 0, or the value a gate gave up waiting for (the gradients of that step are wrong). */
+ * (no event record on the caller's stream; EAE_FORK_EVENTS=1 restores events).  Their spin is bounded by wall-clock time (30 s;
+ * EAE_GATE_TIMEOUT_MS=<ms>, 0 = unbounded), so a caller's stream stalled for seconds in front of a step is simply waited for.
+ * A gate that gives up sets a STICKY device word: from then on every optimizer kernel of the context leaves the parameters
+ * untouched and writes NaN into the step's loss_last (the gradients of that step may come from stale activations).
+ * eae_gate_timeouts synchronises the device and returns 0, or the value a gate gave up waiting for; eae_gate_timeouts_clear
+ * resets the word once the caller has dealt with the failed step.  Replaces nothing in the reference (R.md:642-658 runs on one
+ * in-order stream); it guards the engine's own side-stream concurrency. */
 long long eae_gate_timeouts(eae_ctx* ctx);
+long long eae_gate_timeouts_nosync(eae_ctx* ctx);   /* same word, no device synchronisation (the caller has synchronised its own stream) */
+int eae_gate_timeouts_clear(eae_ctx* ctx);
 /* The host changed parameter values (load_state_dict, optimizer outside the engine): repack before next use. */
 int eae_params_changed(eae_ctx* ctx);
 int eae_set_adam_step(eae_ctx* ctx, long long step);

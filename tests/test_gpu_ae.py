@@ -274,6 +274,11 @@ def test_num_classes_other_than_10_vs_oracle():
         got_g = dict(m.named_parameters())[name].grad.cpu().numpy()
         assert got_g.shape == gq[name].shape
         assert G.cosine(got_g, gq[name]) > 0.995, (name, G.cosine(got_g, gq[name]))
+        if name.startswith("classifier"):
+            # the head is fp32 end to end: its gradients differ from the oracle's only through the bf16 rounding of z upstream, so
+            # a wrong SCALE (1/B, a missed class) must show: elementwise and in the norm (cosine alone is scale-blind)
+            nr = np.linalg.norm(got_g.ravel().astype(np.float64)) / np.linalg.norm(gq[name].ravel().astype(np.float64))
+            assert G.relmax(got_g, gq[name]) <= 2e-2 and 0.99 <= nr <= 1.01, (name, G.relmax(got_g, gq[name]), nr)
     with pytest.raises(Exception, match="num_classes"):
         _engine(eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=65).cuda(), max_batch=4)
 
@@ -299,6 +304,15 @@ def test_adam_trajectory_vs_golden(golden, tag, head):
     np.testing.assert_allclose(np.array(losses)[4], g["losses"][4], rtol=0.2)
     sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     assert int(sd["enc.encoder.1.num_batches_tracked"]) == 5
+    # How far does the SAME arithmetic with bf16 storage drift from the fp32 reference on this trajectory?  The NumPy oracle with bf16
+    # emulation is run through the same five steps here (2 s of CPU) and its own per-buffer deviation from the golden is the yardstick
+    # for the running statistics below (the bound is justified by a measured spread, not by a constant).
+    po = {k: v.copy() for k, v in ae_state_np().items()}
+    so = O.new_adam_state()
+    for step in range(5):
+        x, y = gu.make_images(8, 200 + step)
+        O.ae_train_step(po, so, x, y, alpha, lr, quant="bf16", head=head)
+    spread = {k[4:]: float(np.abs(po[k[4:]] - g[k]).max()) for k in g.files if k.startswith("buf/") and "running" in k}
     # final/* weights and BatchNorm buffers of the reference after the 5 steps.  Every step moves a weight by about +-lr, so two
     # runs that disagree on the sign of a near-zero gradient differ by up to 2*5*lr there (measured max 0.041 = 8.3 lr); what
     # the bound catches is a wrong update size, a missed tensor or a wrong buffer, not bf16 noise.
@@ -314,7 +328,11 @@ def test_adam_trajectory_vs_golden(golden, tag, head):
         elif "running" in name:            # measured: mean |d| <= 0.11, var <= 12 % of its max (8x8x8 samples per channel at b=8);
             # 19 % on single channels of one layer with another tile geometry (the trajectory is chaotic, see above): the
             # per-channel bound is loose, and the norm of the whole buffer is held to 15 % (measured up to 8.4 %)
-            ok = np.abs(s - smp).max() <= 0.25 * np.abs(smp).max() + 0.12 and 0.85 <= d[1] / max(dg[1], 1e-30) <= 1.15
+            # Bound per buffer: twice the oracle's own drift (floor: 2 % of the buffer's max + 0.01).  Measured drift of the oracle after
+            # 5 steps: up to 0.78 (22 % of max) on dec.decoder.2.running_var, 0.12 (33 %) on enc.encoder.10.running_mean, < 1 % on
+            # the first layers -- the old flat 25 %-of-max bound was looser than this on 11 of the 14 buffers.
+            full = np.abs(sd[name] - g[f"buf/{name}"]).max()
+            ok = full <= max(2.0 * spread[name], 0.02 * np.abs(g[f"buf/{name}"]).max() + 0.01) and 0.85 <= d[1] / max(dg[1], 1e-30) <= 1.15
         elif gu.is_prebn_bias(name) or (not head and name.startswith("classifier")):
             ok = True                      # zero-gradient biases: the reference random-walks them, the engine keeps them
         else:
@@ -819,3 +837,252 @@ def test_non_finite_input_poisons_the_step_like_the_reference():
     got = e3.forward(_cuda(x2), labels=_cuda(y2), train=True, alpha=35.0)
     torch.cuda.synchronize()
     assert torch.equal(got[2], ref[2]) and torch.equal(got[0], ref[0])
+
+
+def _stall(seconds):
+    """Keep the CURRENT stream busy for about `seconds` (torch.cuda._sleep spins for a number of device clock ticks: calibrated here)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    probe = 20_000_000
+    torch.cuda.synchronize()
+    e0.record(); torch.cuda._sleep(probe); e1.record()
+    torch.cuda.synchronize()
+    per_tick = e0.elapsed_time(e1) * 1e-3 / probe
+    torch.cuda._sleep(int(seconds / per_tick))
+
+
+def test_caller_stream_stalled_for_seconds_in_front_of_a_step_is_waited_for():
+    """the side-stream gates used to give up after ~2 s and let the weight-gradient kernels run before the kernels
+    they depend on.  The spin is now bounded by 30 s of wall clock: a step enqueued behind a 2.6 s stall of the caller's stream
+    (a late data-parallel peer, a long copy) produces the same gradients, bit for bit, as an unstalled one."""
+    x, y = gu.make_images(8, 321)
+    ma, mb = _model(), _model()
+    ea, eb = _engine(ma), _engine(mb)
+    xd, yd = _cuda(x), _cuda(y)           # (device copies BEFORE the stall: a pageable H2D copy would wait for the stalled stream on the host)
+    ea.grad_step(xd, yd, 35.0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _stall(2.6)
+    eb.grad_step(xd, yd, 35.0)
+    e1.record()
+    torch.cuda.synchronize()
+    assert e0.elapsed_time(e1) > 2300.0     # the step really was enqueued behind the stall
+    assert eb.gate_timeouts() == 0
+    assert torch.equal(ea.grads, eb.grads)
+
+
+def test_a_gate_timeout_is_loud(monkeypatch):
+    """... and a gate that does time out (bound lowered to 100 ms for this context) cannot go unnoticed: the sticky word makes the
+    optimizer kernel leave the parameters untouched and write NaN losses, check_gates() / AEStepper.end() raise."""
+    from eae_amd._lib import EaeError
+    from eae_amd.train import AEStepper
+    monkeypatch.setenv("EAE_GATE_TIMEOUT_MS", "100")
+    x, y = gu.make_images(8, 321)
+    m = _model()
+    eng = _engine(m)
+    monkeypatch.delenv("EAE_GATE_TIMEOUT_MS")
+    xd, yd = _cuda(x), _cuda(y)
+    eng.train_step(xd, yd, 35.0, 5e-3)          # a normal step first
+    torch.cuda.synchronize()
+    assert eng.gate_timeouts() == 0 and np.isfinite(float(eng.loss_last[0]))
+    p0 = eng.params.clone()
+    _stall(0.8)
+    eng.train_step(xd, yd, 35.0, 5e-3)
+    torch.cuda.synchronize()
+    assert eng.gate_timeouts() != 0
+    assert torch.equal(eng.params, p0)                       # no update from gradients that may be stale
+    assert np.isnan(float(eng.loss_last[0]))
+    with pytest.raises(EaeError):
+        eng.check_gates()
+    st = AEStepper(m, 35.0, 5e-3, max_batch=64)
+    st.begin()
+    with pytest.raises(EaeError):
+        st.end()
+    eng.clear_gate_timeouts()
+    eng.train_step(xd, yd, 35.0, 5e-3)
+    torch.cuda.synchronize()
+    assert eng.gate_timeouts() == 0 and not torch.equal(eng.params, p0) and np.isfinite(float(eng.loss_last[0]))
+
+
+def test_autograd_half_guards():
+    """(1) an Encoder whose INPUT requires grad must not silently return no input gradient; (2) dec(enc(x)) on the two
+    halves of one SupervisedAutoencoder (one shared engine workspace) is refused at forward time with a pointer to model(x)."""
+    import eae_amd
+    x, y = gu.make_images(4, 5)
+    enc = eae_amd.Encoder(64).cuda().train()
+    xi = _cuda(x).requires_grad_(True)
+    with pytest.raises(RuntimeError, match="does not compute dL/dx"):
+        enc(xi)
+    m = _model(); m.train()
+    z = m.enc(_cuda(x))
+    with pytest.raises(RuntimeError, match="call model"):
+        m.dec(z)
+    # the resident encoder forward is still differentiable after the refused call
+    z.sum().backward()
+    assert m.enc.encoder[0].weight.grad is not None and torch.isfinite(m.enc.encoder[0].weight.grad).all()
+
+
+@pytest.mark.parametrize("b", [64, 512])
+def test_nan_parameter_poisons_the_statistics_at_any_batch_size(b):
+    """non-finite partials used to travel INSIDE the wrapping fixed-point sums (2^61 each): a power-of-two number of poisoned
+    workgroups per accumulator copy cancelled mod 2^64 and the statistics came out finite (mean 0, var 0).  They now set a sticky
+    per-channel flag: a NaN weight of enc.conv2 gives NaN running statistics for its channel and a NaN loss at every batch size."""
+    x, y = gu.make_images(b, 12)
+    m = _model()
+    eng = _engine(m, max_batch=b)
+    with torch.no_grad():
+        m.enc.encoder[3].weight[5, 0, 0, 0] = float("nan")
+    eng.params_changed()
+    eng.forward(_cuda(x), labels=_cuda(y), train=True, alpha=35.0, want=())
+    torch.cuda.synchronize()
+    assert np.isnan(float(eng.loss_last[0]))
+    rv, rm = m.enc.encoder[4].running_var, m.enc.encoder[4].running_mean
+    assert bool(torch.isnan(rv[5])) and bool(torch.isnan(rm[5]))
+    assert bool(torch.isfinite(rv[:5]).all()) and bool(torch.isfinite(rv[6:]).all())      # like the reference: only that channel
+    assert bool(torch.isnan(m.enc.encoder[7].running_var).all())                           # downstream layers mix the channels
+
+
+def test_two_adam_steps_running_statistics_vs_golden(golden):
+    """BatchNorm running statistics at a TIGHT tolerance, before the Adam trajectory turns chaotic.  Reference run:
+    two joint steps at B=32 with every buffer recorded after each (tests/golden/ae_adam2_bn_b32.npz, tools/make_golden.py --round3).
+    After step 1 the buffers only depend on the forward: momentum 0.1, UNBIASED variance, num_batches_tracked -- held to 5e-3 of the
+    buffer's max (the bf16-emulating oracle measures 8.7e-4).  After step 2 the weights have moved by +-lr: the bf16 oracle itself is
+    5.9e-2 off on its worst buffer, so each buffer is held to max(2e-2, 2 x the oracle's own deviation measured here) of its max."""
+    g = golden("ae_adam2_bn_b32.npz")
+    alpha, lr = float(g["alpha"]), float(g["lr"])
+    m = _model()
+    eng = _engine(m)
+    po = {k: v.copy() for k, v in ae_state_np().items()}
+    so = O.new_adam_state()
+    for step in (1, 2):
+        x, y = gu.make_images(32, 800 + step - 1)
+        eng.train_step(_cuda(x), _cuda(y), alpha, lr)
+        torch.cuda.synchronize()
+        O.ae_train_step(po, so, x, y, alpha, lr, quant="bf16")
+        assert abs(float(eng.loss_last[0]) - float(g["losses"][step - 1])) <= 1e-2 * float(g["losses"][step - 1])
+        sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        bad = []
+        for k in g.files:
+            if not k.startswith(f"step{step}/"):
+                continue
+            name = k.split("/", 1)[1]
+            if name.endswith("num_batches_tracked"):
+                assert int(sd[name]) == step == int(g[k])
+                continue
+            ref = g[k]
+            scale = np.abs(ref).max()
+            dev = np.abs(sd[name] - ref).max() / scale
+            odev = np.abs(po[name] - ref).max() / scale
+            tol = 5e-3 if step == 1 else max(2e-2, 2.0 * odev)
+            if not dev <= tol:
+                bad.append((name, float(dev), float(odev), tol))
+        assert not bad, (step, bad)
+
+
+def test_config2_batch256_reconstruction_only_properties_and_torch_cpu_port():
+    """BASELINE configs[1] at its FULL size (B=256, encoder + decoder, MSE only; bench.py's `configs.c2`): the reference holds a
+    golden for this mode at b=8 only (ae_adam5_recon_b8.npz), so at 256: (1) eval forward is per-image (one call == four B=64 calls,
+    bitwise); (2) the gradient of alpha*MSE is linear in alpha; (3) two identical gradient steps are bitwise equal and the classifier
+    receives exactly zero gradient; (4) loss, x_hat and every gradient against the torch-CPU port of the reference graph
+    (oracle/ae_torch_cpu.py, fp32) at the same size -- one CPU step of 256 images is cheap enough."""
+    import gpu_util as G
+    from oracle import ae_torch_cpu as T
+    x, y = gu.make_images(256, 4242)
+    xd, yd = _cuda(x), _cuda(y)
+    m = _model()
+    eng = _engine(m, max_batch=256)
+    m.eval()
+    xh, _, z = eng.forward(xd, train=False, head=False, want=("x_hat", "z"))
+    torch.cuda.synchronize()
+    for k in range(0, 256, 64):
+        xh_k, _, z_k = eng.forward(xd[k:k + 64].contiguous(), train=False, head=False, want=("x_hat", "z"))
+        torch.cuda.synchronize()
+        assert torch.equal(z_k, z[k:k + 64]) and torch.equal(xh_k, xh[k:k + 64]), k
+    grads = {}
+    for alpha in (1.0, 2.0, 1.0):
+        m2 = _model()
+        e2 = _engine(m2, max_batch=256)
+        x_hat = torch.empty_like(xd)
+        e2.grad_step(xd, yd, alpha, head=False, x_hat=x_hat)
+        torch.cuda.synchronize()
+        gnp = e2.grads.cpu().numpy().copy()
+        if alpha in grads:
+            assert np.array_equal(grads[alpha][0], gnp)                                  # (3)
+        grads[alpha] = (gnp, float(e2.loss_last[1]), x_hat.cpu().numpy(), e2)
+    g1, g2 = grads[1.0][0], grads[2.0][0]
+    assert G.cosine(g2, 2.0 * g1) > 0.9995 and G.relmax(g2, 2.0 * g1) < 3e-2, (G.cosine(g2, 2.0 * g1), G.relmax(g2, 2.0 * g1))   # (2)
+    e2 = grads[1.0][3]
+    assert float(e2.grads[e2.poff[34]:e2.poff[38]].abs().max()) == 0.0                   # (3) head untouched
+    # (4) the torch-CPU port (fp32) on the same batch
+    pt = T.build(latent_dim=64, state=ae_state_np())
+    xt = torch.from_numpy(x)
+    out = T.forward(pt, xt, train=True, head=False)
+    xh_ref = out[0] if isinstance(out, tuple) else out
+    loss = torch.nn.functional.mse_loss(xh_ref, xt)
+    loss.backward()
+    assert abs(grads[1.0][1] - float(loss)) <= 2e-2 * float(loss), (grads[1.0][1], float(loss))
+    d = np.abs(grads[1.0][2] - xh_ref.detach().numpy())
+    assert d.max() <= 3e-2 and d.mean() <= 3e-3, (d.max(), d.mean())
+    slot_of = {id(q): j for q, j in e2._slots}
+    bad = []
+    for name, prm in e2.root_ref().named_parameters():
+        if name.startswith("classifier") or name in PRE_BN_BIAS:
+            continue
+        i = slot_of[id(prm)]
+        got = g1[e2.poff[i]: e2.poff[i] + prm.numel()].reshape(tuple(prm.shape))
+        ref = pt[name].grad.numpy()
+        c = G.cosine(got, ref)
+        nr = np.linalg.norm(got.ravel().astype(np.float64)) / max(np.linalg.norm(ref.ravel().astype(np.float64)), 1e-30)
+        if not (c > 0.97 and 0.93 <= nr <= 1.07):
+            bad.append((name, c, nr))
+    assert not bad, bad
+
+
+def test_config5_benchmarked_geometry_b128_properties():
+    """bench.py times BASELINE configs[4]'s per-GPU shape at B=128 (256x256 inputs, 256-d latent); the oracle checks of that shape
+    run at B=2 / 8 (a different igemm grid geometry: the small-tile rule of eae_conv_launch.hip depends on the batch).  At the
+    benchmarked geometry: (1) eval forward per image (one B=128 call == two B=64 calls, bitwise); (2) two gradient steps from the
+    same state are bitwise equal, bf16 and fp8; (3) the fp8 variant's gradients stay close to the bf16 ones (cosine, norm) and are
+    not identical to them.  No reference vector exists for this shape (R.md:309): parity unpinned by the reference."""
+    import eae_amd
+    import gpu_util as G
+    from eae_amd.engine import AEEngine
+    g = torch.Generator(device="cuda"); g.manual_seed(99)
+    x = torch.rand((128, 3, 256, 256), generator=g, device="cuda")
+    y = torch.randint(0, 10, (128,), generator=g, device="cuda")
+
+    def make(quant):
+        torch.manual_seed(6)
+        m = eae_amd.SupervisedAutoencoder(latent_dim=256, num_classes=10, image_size=256).cuda().train()
+        return m, AEEngine(m, max_batch=128, quant=quant)
+
+    m, eng = make("bf16")
+    m.eval()
+    xh, lg, z = eng.forward(x, labels=y, train=False, alpha=35.0)
+    torch.cuda.synchronize()
+    for k in (0, 64):
+        xh_k, lg_k, z_k = eng.forward(x[k:k + 64].contiguous(), labels=y[k:k + 64].contiguous(), train=False, alpha=35.0)
+        torch.cuda.synchronize()
+        assert torch.equal(z_k, z[k:k + 64]) and torch.equal(lg_k, lg[k:k + 64]) and torch.equal(xh_k, xh[k:k + 64]), k
+    del eng, m
+    got = {}
+    for quant in ("bf16", "fp8"):
+        runs = []
+        for _ in range(2):
+            m, eng = make(quant)
+            if quant == "fp8":
+                eng.fp8_calibrate(x, y, 35.0)
+            eng.grad_step(x, y, 35.0)
+            torch.cuda.synchronize()
+            assert eng.gate_timeouts() == 0
+            runs.append((eng.grads.cpu().numpy().copy(), float(eng.loss_last[0])))
+            del eng, m
+            torch.cuda.empty_cache()
+        assert np.array_equal(runs[0][0], runs[1][0]), quant                            # (2)
+        assert np.isfinite(runs[0][1])
+        got[quant] = runs[0]
+    gb, gf = got["bf16"][0], got["fp8"][0]
+    assert not np.array_equal(gb, gf)
+    nr = np.linalg.norm(gf.astype(np.float64)) / np.linalg.norm(gb.astype(np.float64))
+    assert G.cosine(gf, gb) > 0.95 and 0.88 <= nr <= 1.12, (G.cosine(gf, gb), nr)         # (3)
+    assert abs(got["fp8"][1] - got["bf16"][1]) <= 3e-2 * abs(got["bf16"][1])

@@ -112,6 +112,13 @@ def _sync_worker(rank, world, initfile, outdir):
         tr.train_step(xs, ys, ALPHA, LR)
     torch.cuda.synchronize()
     np.save(os.path.join(outdir, f"syncp_{rank}.npy"), eng.params.cpu().numpy())
+    # uneven shards (a short last batch on one rank) must be refused, on every rank, before any statistics are exchanged
+    msg = ""
+    try:
+        tr.train_step(xs[: h - 4 * rank].contiguous(), ys[: h - 4 * rank].contiguous(), ALPHA, LR)
+    except RuntimeError as e:
+        msg = str(e)
+    open(os.path.join(outdir, f"uneven_{rank}.txt"), "w").write(msg)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -125,6 +132,8 @@ def test_sync_bn_world2_equals_single_process_global_batch():
         mp.spawn(_sync_worker, args=(2, os.path.join(d, "init"), d), nprocs=2, join=True)
         r = [np.load(os.path.join(d, f"sync_{k}.npz")) for k in range(2)]
         p = [np.load(os.path.join(d, f"syncp_{k}.npy")) for k in range(2)]
+        uneven = [open(os.path.join(d, f"uneven_{k}.txt")).read() for k in range(2)]
+    assert all("same per-rank batch size" in u for u in uneven), uneven
     m = _model(); m.train()
     eng = engine_for(m, max_batch=SB)
     x, y = gu.make_images(SB, 950)

@@ -1,0 +1,88 @@
+"""Grid-level execution (SURVEY.md 8f N2, R.md:599-711): K configurations of the reference's alpha x lr grid trained CONCURRENTLY on
+one GPU -- one engine context per configuration, each on its own stream, stepped from its own host thread -- give, for every
+configuration, bitwise the curves and final weights of the same configuration trained alone."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _loaders():
+    tr = [(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()) for x, y in (gu.make_images(b, 1300 + i) for i, b in enumerate((64, 64, 48)))]
+    va = [(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()) for x, y in (gu.make_images(b, 1400 + i) for i, b in enumerate((64, 56)))]
+    return tr, va
+
+
+def test_concurrent_grid_configs_are_bitwise_the_sequential_ones(tmp_path):
+    import eae_amd
+    from eae_amd import train as T
+    tr, va = _loaders()
+    lock = threading.Lock()
+    store = {}
+
+    def fit(tag):
+        def fit_fn(train_loader, val_loader, alpha, lr, **kw):
+            with lock:                                   # the module initialisers draw from torch's GLOBAL generator
+                torch.manual_seed(1000 + int(alpha) * 7 + int(lr * 1e4))
+                model = eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=10).cuda()
+            kw.pop("model", None)
+            r = T.fit_autoencoder(train_loader, val_loader, alpha, lr, model=model, **kw)
+            store[(tag, alpha, lr)] = (list(r["train_curve"]), list(r["val_curve"]),
+                                       {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
+            return r
+        return fit_fn
+
+    kw = dict(alpha_values=(20, 35), lr_values=(1e-3, 5e-3), num_epochs=2, patience=15, verbose=False)
+    seq = T.grid_search_autoencoder(tr, va, out_dir=str(tmp_path / "seq"), fit_fn=fit("seq"), concurrent=1, **kw)
+    con = T.grid_search_autoencoder(tr, va, out_dir=str(tmp_path / "con"), fit_fn=fit("con"), concurrent=4, **kw)
+    assert seq["results"] == con["results"] and (seq["best_alpha"], seq["best_lr"]) == (con["best_alpha"], con["best_lr"])
+    for alpha in (20, 35):
+        for lr in (1e-3, 5e-3):
+            a, b = store[("seq", alpha, lr)], store[("con", alpha, lr)]
+            assert a[0] == b[0] and a[1] == b[1], (alpha, lr, a[:2], b[:2])
+            assert np.isfinite(a[0]).all() and a[0][-1] < a[0][0]
+            for k in a[2]:
+                assert np.array_equal(a[2][k], b[2][k]), (alpha, lr, k)
+    sa, sb = torch.load(seq["best_path"]), torch.load(con["best_path"])
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+
+
+def test_concurrent_steps_from_threads_scale_and_stay_deterministic():
+    """K engines stepped from K threads (train.run_concurrent): same parameters as the same steps issued from one thread."""
+    import eae_amd
+    from eae_amd import train as T
+    from eae_amd.engine import engine_for
+    x, y = gu.make_images(64, 77)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+
+    def make(i):
+        torch.manual_seed(50 + i)
+        m = eae_amd.SupervisedAutoencoder(64).cuda().train()
+        return m, engine_for(m, max_batch=64)
+
+    ref = []
+    for i in range(4):
+        m, e = make(i)
+        for _ in range(5):
+            e.train_step(xd, yd, 35.0, 1e-3)
+        torch.cuda.synchronize()
+        ref.append(e.params.clone())
+    pairs = [make(i) for i in range(4)]
+
+    def job_of(e):
+        def job():
+            for _ in range(5):
+                e.train_step(xd, yd, 35.0, 1e-3)
+            return e.gate_timeouts()
+        return job
+
+    touts = T.run_concurrent([job_of(e) for _, e in pairs], 4)
+    torch.cuda.synchronize()
+    assert touts == [0, 0, 0, 0]
+    for i, (_, e) in enumerate(pairs):
+        assert torch.equal(e.params, ref[i]), i

@@ -65,6 +65,37 @@ def test_grid_search_bookkeeping(tmp_path):
     assert js == {"alpha=20, lr=0.1": 3.0, "alpha=20, lr=0.2": 2.5, "alpha=30, lr=0.1": 2.5, "alpha=30, lr=0.2": 2.7}
 
 
+def test_grid_search_concurrent_same_bookkeeping_and_log_order(tmp_path):
+    """concurrent=K runs the configurations on K host threads (each on its own stream on a GPU): the results table, the winner
+    (first strict minimum in GRID order, R.md:702) and the log (a configuration's lines together, in grid order) are those of the
+    sequential loop, whatever order the threads finish in."""
+    import threading
+    import time
+    table = {(20, 0.1): 3.0, (20, 0.2): 2.5, (30, 0.1): 2.5, (30, 0.2): 2.7}
+    seen = []
+
+    def fake_fit(tr, va, alpha, lr, log=print, **kw):
+        time.sleep(0.05 if alpha == 20 else 0.0)              # the first row finishes LAST
+        seen.append(threading.get_ident())
+        log(f"[AE α={alpha} LR={lr}] Epoch 1 | TrainLoss=1.0000 | ValLoss={table[(alpha, lr)]:.4f}")
+        return {"model": None, "train_curve": [1.0], "val_curve": [table[(alpha, lr)]], "best_val_loss": table[(alpha, lr)], "epochs": 1}
+
+    logs = {}
+    outs = {}
+    for k in (1, 4):
+        seen.clear()
+        logs[k] = []
+        d = tmp_path / f"k{k}"
+        outs[k] = T.grid_search_autoencoder([], [], alpha_values=(20, 30), lr_values=(0.1, 0.2), out_dir=str(d), verbose=True, fit_fn=fake_fit,
+                                            log=logs[k].append, concurrent=k, device="cpu")
+        if k > 1:
+            assert len(set(seen)) > 1                            # really ran on several threads
+    assert logs[1] == logs[4]
+    assert (outs[4]["best_alpha"], outs[4]["best_lr"]) == (outs[1]["best_alpha"], outs[1]["best_lr"]) == (20, 0.2)
+    assert outs[4]["results"] == outs[1]["results"]
+    assert json.load(open(tmp_path / "k4" / "validation_losses.json")) == json.load(open(tmp_path / "k1" / "validation_losses.json"))
+
+
 class ScriptedMLP:
     device = None
 

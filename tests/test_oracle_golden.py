@@ -245,6 +245,27 @@ def test_ae_one_adam_step(golden):
         assert np.mean(np.abs(s - g[k]) < 1e-4) > 0.97, (name, np.abs(s - g[k]).max())
 
 
+def test_ae_two_steps_running_statistics(golden):
+    """ae_adam2_bn_b32.npz (round 3): BatchNorm buffers of the reference after each of two joint Adam steps at B=32.  Step 1 pins the
+    oracle's momentum / unbiased-variance / counter arithmetic to fp32 noise; after step 2 the weights have moved by +-lr (Adam's
+    sign-like first step), where fp32 summation order alone gives 6e-3 of a buffer's max."""
+    g = golden("ae_adam2_bn_b32.npz")
+    p = {k: v.copy() for k, v in ae_state_np().items()}
+    st = O.new_adam_state()
+    for step in (1, 2):
+        x, y = gu.make_images(32, int(g["seed0"]) + step - 1)
+        loss = O.ae_train_step(p, st, x, y, float(g["alpha"]), float(g["lr"]))[0]
+        assert abs(loss - g["losses"][step - 1]) <= (1e-5 if step == 1 else 2e-3) * g["losses"][step - 1]
+        for k in g.files:
+            if not k.startswith(f"step{step}/"):
+                continue
+            name = k.split("/", 1)[1]
+            if name.endswith("num_batches_tracked"):
+                assert int(p[name]) == int(g[k]) == step
+            else:
+                assert _relerr(p[name], g[k]) <= (1e-5 if step == 1 else 2e-2), (step, name, _relerr(p[name], g[k]))
+
+
 def test_mlp_forward_backward(golden):
     g = golden("mlp_fwd_bwd_b64.npz")
     p = mlp_state_np()

@@ -17,9 +17,9 @@ lib = _lib.load()
 raw = C.CDLL(_lib.LIB_PATH)
 B = 512
 dev = torch.device("cuda:0")
-dbg = torch.zeros(64, dtype=torch.int64, device=dev)
+dbg = torch.zeros(32768, dtype=torch.int64, device=dev)     # [0,64): phase stamps; beyond: the per-workgroup stamps of EAE_STAMP_WG
 names = ["loads issued+coef", "transform+LDSwrite", "barrier", "MFMA(last chunk)", "barrier", "tile+rows(all ph)", "stats reduce"]
-CASES = ((0, 32, 64, 32, 1, 0), (0, 64, 128, 16, 1, 0), (0, 128, 256, 8, 1, 0), (1, 128, 64, 8, 1, 0), (1, 64, 32, 16, 1, 0),
+CASES = ((0, 32, 64, 32, 1, 0), (0, 64, 128, 16, 1, 0), (0, 128, 256, 8, 1, 0), (1, 256, 128, 4, 0, 0), (1, 128, 64, 8, 1, 0), (1, 64, 32, 16, 1, 0),
          (1, 64, 32, 16, 2, 1), (0, 32, 64, 32, 2, 1))       # (kind, cin, cout, hin, source mode, epilogue)
 for (kind, ci, co, hin, smode, epi) in CASES:
     x = (torch.randn((B, hin, hin, ci), device=dev) * 0.5).to(torch.bfloat16)

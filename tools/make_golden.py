@@ -152,10 +152,43 @@ def gen_latent48(ref):
     print(f"  ae_latent48_b8.npz: {os.path.getsize(os.path.join(OUT, 'ae_latent48_b8.npz')) / 1e6:.2f} MB")
 
 
+def gen_round3(ref):
+    """`python tools/make_golden.py --round3`: ae_adam2_bn_b32.npz -- TWO Adam steps of the joint loss at B=32 (R.md:642-658) with every
+    BatchNorm buffer recorded after each step.  Two steps in, the trajectory has not gone chaotic yet (the 5-step fixture has), so a
+    wrong momentum, a biased-instead-of-unbiased running variance or a missed num_batches_tracked shows at a tight tolerance."""
+    SAE = ref["SupervisedAutoencoder"]
+    torch.manual_seed(gu.AE_SEED)
+    m = SAE(latent_dim=64, num_classes=10)
+    load_np(m, gu.perturb_bn(sd_np(m)))
+    m.train()
+    alpha, lr = 35.0, 5e-3
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    st = {"alpha": np.float32(alpha), "lr": np.float32(lr), "batch": np.int64(32), "seed0": np.int64(800)}
+    losses = []
+    for step in range(2):
+        x, y = gu.make_images(32, 800 + step)
+        xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+        opt.zero_grad()
+        xh, lg, _ = m(xt)
+        loss = alpha * nn.MSELoss()(xh, xt) + nn.CrossEntropyLoss()(lg, yt)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        for k, v in m.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                st[f"step{step + 1}/{k}"] = v.numpy().copy()
+    st["losses"] = np.array(losses, np.float32)
+    np.savez_compressed(os.path.join(OUT, "ae_adam2_bn_b32.npz"), **st)
+    print(f"  ae_adam2_bn_b32.npz: {os.path.getsize(os.path.join(OUT, 'ae_adam2_bn_b32.npz')) / 1e6:.3f} MB")
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
+    if "--round3" in sys.argv:
+        gen_round3(ref)
+        return
     if "--round2" in sys.argv:
         gen_round2(ref)
         return
@@ -352,6 +385,8 @@ def main():
     X, Y = ref["extract_features"](loader, m.enc)
     np.savez_compressed(os.path.join(OUT, "extract_features.npz"), X=X.numpy(), y=Y.numpy())
     gen_round2(ref)
+    gen_latent48(ref)
+    gen_round3(ref)
     print("fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1e6:.2f} MB")
