@@ -141,7 +141,7 @@ def config5_leg(batch=128, steps=20, warmup=5):
     return res
 
 
-def grid_b64_leg(k=8, steps=150, warmup=15):
+def grid_b64_leg(k=int(os.environ.get("EAE_GRID_K", "4")), steps=150, warmup=15):
     """The reference's REAL workload (R.md:246, 599-711): batch 64, a grid of independent configurations.  K engine contexts, each on
     its own stream and stepped from its own host thread (train.run_concurrent -- what grid_search_autoencoder(concurrent=K) uses), run
     the joint train step at B=64 at the same time; `images_per_s` is the aggregate over the K configurations, `k1` the same loop with
@@ -152,12 +152,16 @@ def grid_b64_leg(k=8, steps=150, warmup=15):
     res = {"workload": "BASELINE configs[2]'s step at the notebook's batch size 64 (R.md:246): K independent (alpha, lr) configurations of "
                        "the grid R.md:599-711 trained concurrently on one GPU, one engine context + stream + host thread each", "batch": 64}
     x, y = make_batch(64, torch.device("cuda"), seed=4321)
+    graph = os.environ.get("EAE_GRID_GRAPH", "0") == "1"      # replay measured slower than eager here (0.7-0.8x): see train.grid_search_autoencoder
+    res["graph_replay"] = graph
     for kk in (1, k):
         engs = []
         for i in range(kk):
             torch.manual_seed(100 + i)
             m = eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=10).cuda().train()
-            engs.append((m, engine_for(m, max_batch=64)))
+            e = engine_for(m, max_batch=64)
+            e.set_graph(graph and kk > 1)         # K concurrent configurations are bound by the host's launch rate: one replay per step
+            engs.append((m, e))
 
         def job_of(e, n):
             def job():
@@ -267,6 +271,13 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(loss, 4)},
         }
+        if trainer is not None:
+            # ranks of the RCCL communicator the ENGINE owns (eae_dp_init): the driver's SCALE record can confirm that N ranks exchanged
+            out["rccl_ranks"] = trainer.rccl_ranks()
+            out["config"]["dp_exchange"] = ("engine-owned RCCL communicator, decoder-side bucket overlapped with the encoder backward"
+                                            if trainer.native and os.environ.get("EAE_DP_OVERLAP", "1") != "0" else
+                                            "engine-owned RCCL communicator, one all-reduce after the backward" if trainer.native else
+                                            "torch.distributed all-reduce")
         # step-level roofline context
         step_bytes = args.batch * BYTES_PER_IMG_BF16 + BYTES_PER_STEP_WEIGHTS
         out["step_roofline"] = {"hbm_floor_us": round(step_bytes / (HBM_PEAK_GBS * 1e3), 1),

@@ -44,6 +44,7 @@ _PROTOS = {
     "eae_fp8_calibrate": (C.c_int, [vp, vp, vp, C.c_int]),
     "eae_fp8_scales": (C.c_int, [vp, vp]),
     "eae_params_changed": (C.c_int, [vp]),
+    "eae_set_graph": (C.c_int, [vp, C.c_int]),
     "eae_set_adam_step": (C.c_int, [vp, C.c_longlong]),
     "eae_get_adam_step": (C.c_longlong, [vp]),
     "eae_ae_forward": (C.c_int, [vp, vp, C.POINTER(EaeStepIO)]),
@@ -56,6 +57,13 @@ _PROTOS = {
     "eae_side_stream": (vp, [vp]),
     "eae_dp_stream": (vp, [vp, C.c_int]),
     "eae_adam_step_scaled": (C.c_int, [vp, vp, C.c_float, C.c_float, C.c_float]),
+    "eae_dp_unique_id": (C.c_int, [vp]),
+    "eae_dp_init": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    "eae_dp_world": (C.c_int, [vp]),
+    "eae_dp_destroy": (C.c_int, [vp]),
+    "eae_dp_allreduce_bucket": (C.c_int, [vp, vp, C.c_longlong, C.c_longlong]),
+    "eae_dp_broadcast": (C.c_int, [vp, vp, vp, C.c_longlong, C.c_int]),
+    "eae_ae_dp_train_step": (C.c_int, [vp, vp, C.POINTER(EaeStepIO), C.c_float, C.c_int]),
     "eae_ae_train_step": (C.c_int, [vp, vp, C.POINTER(EaeStepIO), C.c_float]),
     "eae_sync_bn_acc_elems": (C.c_longlong, [vp]),
     "eae_set_sync_bn": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),

@@ -109,6 +109,11 @@ struct eae_ctx {
   // dec.fc) and #1 after tensors 8..17 (enc.fc, conv4, conv3); tensors 0..7 are complete when the step's join is reached
   hipStream_t dp_stream[2] = {nullptr, nullptr};
   hipEvent_t ev_part[2] = {nullptr, nullptr};
+  // RCCL communicator owned by the engine (eae_dp_init): the gradient all-reduce is enqueued by the engine itself, no host
+  // code between the backward and the collective
+  void* dp_comm = nullptr;
+  int dp_rank = 0, dp_world = 0;
+  hipEvent_t ev_dp_done = nullptr;
   // folded BatchNorm finalize (forward): fixed-point statistics accumulators per BN layer
   unsigned long long* accf[7] = {};
   int acc_copies[7] = {};
@@ -409,9 +414,11 @@ extern "C" int eae_profile_read2(eae_ctx* c, double* total_ms, double* empty_ms,
 }
 extern "C" int eae_profile_read(eae_ctx* c, double* total_ms, long long* count) { return eae_profile_read2(c, total_ms, nullptr, count); }
 
+extern "C" int eae_dp_destroy(eae_ctx* c);
 extern "C" int eae_destroy(eae_ctx* c) {
   if (!c) return 0;
   hipDeviceSynchronize();
+  eae_dp_destroy(c);
   if (c->prof_ev[0]) for (int i = 0; i < 3 * eae_ctx::PROF_RING; ++i) hipEventDestroy(c->prof_ev[i]);
   for (int i = 0; i < c->ngraphs; ++i) {
     if (c->graphs[i].exec) hipGraphExecDestroy(c->graphs[i].exec);
@@ -483,6 +490,14 @@ extern "C" long long eae_gate_timeouts(eae_ctx* c) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpy(&v, c->sigwords + 8, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (long long)v;
+}
+// hipGraph replay of eae_ae_train_step on/off for this context (default: the EAE_GRAPH environment switch at creation).  One replay per
+// step instead of ~70 launches: the single-configuration step at B=512 is faster eager, but K small configurations
+// stepped concurrently from K host threads are bound by the host's launch rate -- there the replay wins (train.run_concurrent).
+extern "C" int eae_set_graph(eae_ctx* c, int on) {
+  if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL");
+  c->use_graph = on != 0;
+  return 0;
 }
 extern "C" int eae_params_changed(eae_ctx* c) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->packed = false; c->fwd_ready = false; c->fwd_eval_ready = false; c->enc_ready = 0; c->dec_ready = 0; return 0; }
 extern "C" int eae_set_adam_step(eae_ctx* c, long long s) { if (!c) return eae_set_error(EAE_ERR_ARG, "ctx is NULL"); c->adam_step = s; return 0; }
@@ -1392,6 +1407,133 @@ extern "C" int eae_decoder_forward(eae_ctx* c, void* stream, const float* z, int
   RC(copy_latent_in(c, st, c->z, z, B));       // resident for the backward (dec.fc's weight gradient reads z again)
   RC(run_decoder(c, st, c->z, B, train != 0, nullptr, 0.f, x_hat, false, false));
   c->dec_ready = train ? 1 : 2; c->fwd_B = B; c->fwd_gen += 1;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Data parallel over RCCL, driven by the engine (eae_dp_init / eae_dp_allreduce_bucket; 8e).  librccl is bound at
+// run time with dlopen -- the copy torch has already loaded if there is one, so the process holds ONE RCCL --, libeae.so itself
+// keeps no link-time dependency on it.  One communicator per context, one process per GPU.
+//   eae_dp_unique_id   rank 0 draws the 128-byte id (the caller ships it to the other ranks by whatever means it has)
+//   eae_dp_init        every rank: ncclCommInitRank on the context's device
+//   eae_dp_allreduce_bucket   sum over the ranks of gradient-arena elements [off, off + count), in place, on `stream`
+//   eae_ae_dp_train_step      forward + loss + backward + all-reduce + Adam(grad_scale = 1/world) enqueued by ONE call.  overlap=1:
+//                      the decoder-side bucket (gradient tensors 18..37, 3.3 MB at latent 64) is all-reduced on the engine's
+//                      hand-off stream as soon as those tensors are complete, while the encoder half of the backward still runs;
+//                      the encoder-side bucket follows on the caller's stream after the join.  overlap=0: one all-reduce of the
+//                      whole arena after the backward.
+// ---------------------------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and prototypes only; every symbol is resolved with dlsym
+namespace {
+struct RcclApi {
+  void* h = nullptr;
+  decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+  decltype(&ncclCommInitRank) commInitRank = nullptr;
+  decltype(&ncclCommDestroy) commDestroy = nullptr;
+  decltype(&ncclAllReduce) allReduce = nullptr;
+  decltype(&ncclBroadcast) broadcast = nullptr;
+  decltype(&ncclGetErrorString) getErrorString = nullptr;
+  std::string err;
+};
+RcclApi* rccl_api() {
+  static RcclApi api = [] {
+    RcclApi a;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    for (const char* n : names) if (!a.h) a.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the copy already in the process (torch's)
+    for (const char* n : names) if (!a.h) a.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!a.h) a.h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!a.h) { a.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return a; }
+    a.getUniqueId = reinterpret_cast<decltype(a.getUniqueId)>(dlsym(a.h, "ncclGetUniqueId"));
+    a.commInitRank = reinterpret_cast<decltype(a.commInitRank)>(dlsym(a.h, "ncclCommInitRank"));
+    a.commDestroy = reinterpret_cast<decltype(a.commDestroy)>(dlsym(a.h, "ncclCommDestroy"));
+    a.allReduce = reinterpret_cast<decltype(a.allReduce)>(dlsym(a.h, "ncclAllReduce"));
+    a.broadcast = reinterpret_cast<decltype(a.broadcast)>(dlsym(a.h, "ncclBroadcast"));
+    a.getErrorString = reinterpret_cast<decltype(a.getErrorString)>(dlsym(a.h, "ncclGetErrorString"));
+    if (!a.getUniqueId || !a.commInitRank || !a.commDestroy || !a.allReduce || !a.broadcast || !a.getErrorString) a.err = "librccl lacks a required symbol";
+    return a;
+  }();
+  return &api;
+}
+int rccl_fail(RcclApi* r, ncclResult_t e, const char* what) {
+  std::string m = std::string(what) + ": " + (r->getErrorString ? r->getErrorString(e) : "rccl error");
+  return eae_set_error(EAE_ERR_HIP, m.c_str());
+}
+#define RCCL(x, what) do { ncclResult_t e__ = (x); if (e__ != ncclSuccess) return rccl_fail(r, e__, what); } while (0)
+}  // namespace
+
+extern "C" int eae_dp_unique_id(void* id128) {
+  if (!id128) return eae_set_error(EAE_ERR_ARG, "dp_unique_id: NULL");
+  RcclApi* r = rccl_api();
+  if (!r->err.empty()) return eae_set_error(EAE_ERR_STATE, r->err.c_str());
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  RCCL(r->getUniqueId(&id), "ncclGetUniqueId");
+  memcpy(id128, &id, 128);
+  return 0;
+}
+extern "C" int eae_dp_init(eae_ctx* c, int rank, int world, const void* id128) {
+  if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return eae_set_error(EAE_ERR_ARG, "dp_init: bad argument");
+  if (c->dp_comm) return eae_set_error(EAE_ERR_STATE, "dp_init: this context already owns a communicator");
+  RcclApi* r = rccl_api();
+  if (!r->err.empty()) return eae_set_error(EAE_ERR_STATE, r->err.c_str());
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  ncclComm_t comm = nullptr;
+  RCCL(r->commInitRank(&comm, world, id, rank), "ncclCommInitRank");
+  c->dp_comm = comm; c->dp_rank = rank; c->dp_world = world;
+  if (!c->ev_dp_done) EAE_HIP(hipEventCreateWithFlags(&c->ev_dp_done, EV_FLAGS));
+  return 0;
+}
+extern "C" int eae_dp_world(eae_ctx* c) { return c ? c->dp_world : 0; }
+extern "C" int eae_dp_destroy(eae_ctx* c) {
+  if (!c || !c->dp_comm) return 0;
+  RcclApi* r = rccl_api();
+  hipDeviceSynchronize();
+  if (r->commDestroy) r->commDestroy(static_cast<ncclComm_t>(c->dp_comm));
+  c->dp_comm = nullptr; c->dp_world = 0;
+  if (c->ev_dp_done) { hipEventDestroy(c->ev_dp_done); c->ev_dp_done = nullptr; }
+  return 0;
+}
+extern "C" int eae_dp_allreduce_bucket(eae_ctx* c, void* stream, long long elem_off, long long count) {
+  if (!c || !c->dp_comm) return eae_set_error(EAE_ERR_STATE, "dp_allreduce_bucket: eae_dp_init has not been called");
+  if (!c->G || elem_off < 0 || count <= 0 || elem_off + count > c->poff[38]) return eae_set_error(EAE_ERR_ARG, "dp_allreduce_bucket: range outside the gradient arena");
+  RcclApi* r = rccl_api();
+  RCCL(r->allReduce(c->G + elem_off, c->G + elem_off, (size_t)count, ncclFloat, ncclSum, static_cast<ncclComm_t>(c->dp_comm), (hipStream_t)stream),
+       "ncclAllReduce");
+  return 0;
+}
+// identical replicas: `bytes` of any device buffer from rank `root` (parameters, running statistics, Adam moments at start-up)
+extern "C" int eae_dp_broadcast(eae_ctx* c, void* stream, void* buf, long long bytes, int root) {
+  if (!c || !c->dp_comm) return eae_set_error(EAE_ERR_STATE, "dp_broadcast: eae_dp_init has not been called");
+  if (!buf || bytes <= 0 || root < 0 || root >= c->dp_world) return eae_set_error(EAE_ERR_ARG, "dp_broadcast: bad argument");
+  RcclApi* r = rccl_api();
+  RCCL(r->broadcast(buf, buf, (size_t)bytes, ncclChar, root, static_cast<ncclComm_t>(c->dp_comm), (hipStream_t)stream), "ncclBroadcast");
+  c->packed = false;
+  return 0;
+}
+extern "C" int eae_ae_dp_train_step(eae_ctx* c, void* stream, const eae_step_io* io, float lr, int overlap) {
+  RC(check_io(c, io, true));
+  if (!c->dp_comm) return eae_set_error(EAE_ERR_STATE, "dp_train_step: eae_dp_init has not been called");
+  if (!c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: moment arenas must be bound");
+  hipStream_t st = (hipStream_t)stream;
+  const bool ov = overlap != 0 && c->use_side;
+  if (ov && !eae_dp_stream(c, 0)) return eae_set_error(EAE_ERR_HIP, "dp_train_step: cannot create the hand-off stream");
+  c->adam_step += 1;
+  RC(forward_impl(c, st, io, true));
+  RC(backward_impl(c, st, io));             // with a hand-off stream: dp_stream[0] is now ordered after gradient tensors 18..37
+  const long long cut = c->poff[18], total = c->poff[38];
+  if (ov) {
+    RC(eae_dp_allreduce_bucket(c, c->dp_stream[0], cut, total - cut));
+    EAE_HIP(hipEventRecord(c->ev_dp_done, c->dp_stream[0]));
+    RC(eae_dp_allreduce_bucket(c, st, 0, cut));
+    EAE_HIP(hipStreamWaitEvent(st, c->ev_dp_done, 0));
+  } else {
+    RC(eae_dp_allreduce_bucket(c, st, 0, total));
+  }
+  RC(eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f / (float)c->dp_world,
+                            c->acc_base, (long long)c->acc_bytes, c->sigwords + 8, c->last_loss));
+  c->packed = false; c->acc_clean = true;
   return 0;
 }
 

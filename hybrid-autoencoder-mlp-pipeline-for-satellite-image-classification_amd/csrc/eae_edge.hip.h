@@ -7,6 +7,15 @@
 #include "eae_common.hip.h"
 #include "eae_igemm.hip.h"
 
+#ifdef EAE_STAMPS          // diagnostic build: s_memtime stamps of one workgroup of the edge kernels (tools/kstamp3.py)
+__device__ unsigned long long* g_edge_dbg = nullptr;
+__device__ int g_edge_dbg_block = 0;
+#define EDGE_STAMP(i) do { if (g_edge_dbg && (int)blockIdx.x == g_edge_dbg_block && threadIdx.x == 0) { \
+    unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); g_edge_dbg[i] = t__; } } while (0)
+#else
+#define EDGE_STAMP(i) do {} while (0)
+#endif
+
 enum { SRC3_NCHW_F32 = 0,     // fp32 planar image (the loader contract)
        SRC3_NHWC4_BF16 = 1 }; // bf16 pixels padded to 4 channels (gradient of the pre-sigmoid output)
 
@@ -122,7 +131,9 @@ __global__ __launch_bounds__(256) void edge_conv_kernel(EdgeArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
       wf[mt][ks] = *reinterpret_cast<const bf16x8*>(a.c.wpack + (mt * 16 + (lane & 15)) * 64 + ks * 32 + kgl * 8);
+  EDGE_STAMP(16);
   stage_patch3<SRC3>(a.src3, p3, n, a.H, a.W, 2 * tyb * E_TH - 1, 2 * txb * E_TW - 1);      // ends with a barrier
+  EDGE_STAMP(17);
   f32x4 acc[2][2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
@@ -157,12 +168,14 @@ __global__ __launch_bounds__(256) void edge_conv_kernel(EdgeArgs a) {
       *reinterpret_cast<uint2*>(at + m * 40 + ch) = w2;
     }
   }
+  EDGE_STAMP(18);
   __syncthreads();
   auto rowmap = [=](int row) -> long {
     int ty = row / E_TW, tx = row % E_TW;
     return (((long)n * Hout + (tyb * E_TH + ty)) * Wout + (txb * E_TW + tx)) * 32;
   };
   tile_epilogue<32, 32, EPI>(a.c, at, red, 0, blockIdx.x, 128, rowmap);
+  EDGE_STAMP(19);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -315,6 +328,7 @@ __global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
   ChanCoef<SRC> cc;
   BnFoldRegs fr;
   const bool folded = SRC == SRC_BNRELU && a.fold.acc != nullptr;
+  EDGE_STAMP(0);
   if (folded) bn_fold_load<32>(a.fold, fr);       // before the patch loads: results return in issue order
   RawPiece<SRC> raw[NPA];
   bool val[NPA];
@@ -337,13 +351,16 @@ __global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
     }
     cc.load(coefp, 32, kgs * 8);
   }
+  EDGE_STAMP(1);
 #pragma unroll
   for (int i = 0; i < NPA; ++i) {
     int qq = tid + i * 256;
     if (qq < NPIX * 4)
       *reinterpret_cast<uint4*>(patch + (qq >> 2) * PIX_STRIDE + kgs * 8) = transform_piece<SRC>(raw[i], val[i], cc);
   }
+  EDGE_STAMP(2);
   __syncthreads();
+  EDGE_STAMP(3);
   f32x4 acc[2];
   acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -357,12 +374,14 @@ __global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
       acc[mi] = mfma16(af, bfr, acc[mi]);
     }
   }
+  EDGE_STAMP(4);
   __syncthreads();                 // every wave has read its patch fragments: the tiles below overwrite the patch
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int r = 0; r < 4; ++r) sl[((wave * 2 + mi) * 16 + (lane >> 4) * 4 + r) * 17 + (lane & 15)] = acc[mi][r];
   __syncthreads();
+  EDGE_STAMP(5);
   // elementwise pass in NCHW order: e -> (co, oy, ox) over the 8 x 64 x 3 output tile
   float lsum = 0.f, gsum[3] = {0.f, 0.f, 0.f};
   if (a.g4) *reinterpret_cast<uint4*>(gl + tid * 8) = make_uint4(0, 0, 0, 0);   // clears [8*64*4] bf16 = 4 KB
@@ -386,6 +405,7 @@ __global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
       }
     }
   }
+  EDGE_STAMP(6);
   if (a.loss_part) {
     float v[4] = {lsum, gsum[0], gsum[1], gsum[2]};
 #pragma unroll
@@ -402,4 +422,5 @@ __global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
     uint4 v = *reinterpret_cast<const uint4*>(gl + (row * 64 + c2 * 2) * 4);
     *reinterpret_cast<uint4*>(a.g4 + (((size_t)n * Hout + 2 * iy0 + row) * Wout + 2 * ix0 + c2 * 2) * 4) = v;
   }
+  EDGE_STAMP(7);
 }

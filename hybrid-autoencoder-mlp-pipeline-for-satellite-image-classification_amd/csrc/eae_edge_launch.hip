@@ -100,3 +100,12 @@ int eae_launch_sigmoid_bwd(hipStream_t st, const float* x_hat, const float* dx_h
   EAE_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef EAE_STAMPS
+extern "C" int eae_debug_set_edge(void* p, int block) {
+  unsigned long long* q = static_cast<unsigned long long*>(p);
+  EAE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_edge_dbg), &q, sizeof(q)));
+  EAE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_edge_dbg_block), &block, sizeof(block)));
+  return 0;
+}
+#endif

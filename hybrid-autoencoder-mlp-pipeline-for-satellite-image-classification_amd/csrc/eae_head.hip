@@ -16,11 +16,11 @@ constexpr int HC = 64;  // logits row stride in LDS = largest class count
 // float4 feeds 8-32 FMAs:
 //   h_pre [HR][128] = z W1^T        thread = 2 rows x 4 columns (j, j+32, j+64, j+96), K in steps of 4
 //   dz    [HR][L]   = dh W1         thread = 1 row x 4 consecutive k (strided over [HR][L/4]), j = 0..127
-//   dW1   [128][L]  = dh^T z        thread = 8 j x 4 k tiles (strided over [16][L/4]), r = 0..HR-1
+//   dW1   [128][L]  = dh^T z        thread = 4 j x 4 k tiles (strided over [32][L/4]), r = 0..HR-1
 // Row strides are padded to L + 4 / 132 floats: 16-byte aligned rows whose float4 reads by 16 consecutive lanes fall on 16 different
 // bank slots.  Arithmetic stays fp32 fmaf chains (the head is fp32 end to end: <= 5e-5 vs the reference's goldens).
 template <int HR_>
-__global__ EAE_NO_PK __launch_bounds__(256) void head_kernel(HeadArgs a) {
+__global__ EAE_NO_PK __launch_bounds__(256, 5) void head_kernel(HeadArgs a) {     // <= 96 VGPRs: the kernel runs beside the decoder on a side stream, and a wave-specialised igemm2 workgroup (2 x 200 registers per SIMD lane) must still fit beside one of its waves -- at 132 registers dec.deconv1's forward waited for the head's 32 CUs (15 -> 28 us)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int L = a.L, C = a.C, LS = L + 4, HS = 132;
   float* w1 = sm;                    // [128][LS]
@@ -59,7 +59,7 @@ __global__ EAE_NO_PK __launch_bounds__(256) void head_kernel(HeadArgs a) {
       float acc[2][4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) { acc[0][q] = b1[ct + 32 * q]; acc[1][q] = acc[0][q]; }
-#pragma unroll 4
+#pragma unroll 2
       for (int k = 0; k < L; k += 4) {
         const float4 z0 = *reinterpret_cast<const float4*>(zt + (2 * rt) * LS + k), z1 = *reinterpret_cast<const float4*>(zt + (2 * rt + 1) * LS + k);
 #pragma unroll
@@ -79,7 +79,7 @@ __global__ EAE_NO_PK __launch_bounds__(256) void head_kernel(HeadArgs a) {
   for (int i = tid; i < HR_ * C; i += 256) {   // logits
     const int r = i / C, c = i - r * C;
     float s = b2[c];
-#pragma unroll 8
+#pragma unroll 4
     for (int j = 0; j < 128; j += 4) {
       const float4 h = *reinterpret_cast<const float4*>(hp + r * HS + j), w = *reinterpret_cast<const float4*>(w2 + c * HS + j);
       s = fmaf(fmaxf(h.x, 0.f), w.x, s); s = fmaf(fmaxf(h.y, 0.f), w.y, s); s = fmaf(fmaxf(h.z, 0.f), w.z, s); s = fmaf(fmaxf(h.w, 0.f), w.w, s);
@@ -134,14 +134,14 @@ __global__ EAE_NO_PK __launch_bounds__(256) void head_kernel(HeadArgs a) {
   for (int i = tid; i < HR_ * L4; i += 256) {
     const int r = i / L4, k4 = i - r * L4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = 0; j < 128; j += 8) {        // 10 LDS reads in flight per 32 FMAs (a one-read-per-iteration loop exposes the LDS latency 128 times)
-      const float4 d0 = *reinterpret_cast<const float4*>(dh + r * HS + j), d1 = *reinterpret_cast<const float4*>(dh + r * HS + j + 4);
-      const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-      float4 w[8];
+    for (int j = 0; j < 128; j += 4) {        // 5 LDS reads in flight per 16 FMAs (a one-read-per-iteration loop exposes the LDS latency 128 times)
+      const float4 d0 = *reinterpret_cast<const float4*>(dh + r * HS + j);
+      const float d[4] = {d0.x, d0.y, d0.z, d0.w};
+      float4 w[4];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const float4*>(w1 + (j + q) * LS + k4 * 4);
+      for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const float4*>(w1 + (j + q) * LS + k4 * 4);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < 4; ++q) {
         s.x = fmaf(d[q], w[q].x, s.x); s.y = fmaf(d[q], w[q].y, s.y); s.z = fmaf(d[q], w[q].z, s.z); s.w = fmaf(d[q], w[q].w, s.w);
       }
     }
@@ -149,23 +149,23 @@ __global__ EAE_NO_PK __launch_bounds__(256) void head_kernel(HeadArgs a) {
   }
   // partial weight gradients of this block, arena order: W1 [128][L], b1 [128], W2 [C][128], b2 [C] (+pad)
   float* gp = a.grad_part + (size_t)blockIdx.x * a.grad_stride;
-  for (int i = tid; i < 16 * L4; i += 256) {            // dW1: tiles of 8 j x 4 k
+  for (int i = tid; i < 32 * L4; i += 256) {            // dW1: tiles of 4 j x 4 k
     const int jt = i / L4, k4 = i - jt * L4;
-    float4 s[8];
+    float4 s[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 4; ++q) s[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
     for (int r = 0; r < HR_; ++r) {
       const float4 zv = *reinterpret_cast<const float4*>(zt + r * LS + k4 * 4);
-      const float4 d0 = *reinterpret_cast<const float4*>(dh + r * HS + jt * 8), d1 = *reinterpret_cast<const float4*>(dh + r * HS + jt * 8 + 4);
-      const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      const float4 d0 = *reinterpret_cast<const float4*>(dh + r * HS + jt * 4);
+      const float d[4] = {d0.x, d0.y, d0.z, d0.w};
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < 4; ++q) {
         s[q].x = fmaf(d[q], zv.x, s[q].x); s[q].y = fmaf(d[q], zv.y, s[q].y); s[q].z = fmaf(d[q], zv.z, s[q].z); s[q].w = fmaf(d[q], zv.w, s[q].w);
       }
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(gp + (size_t)(jt * 8 + q) * L + k4 * 4) = s[q];
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(gp + (size_t)(jt * 4 + q) * L + k4 * 4) = s[q];
   }
   if (tid < 128) {
     float s = 0.f;

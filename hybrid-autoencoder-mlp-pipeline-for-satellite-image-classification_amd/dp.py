@@ -75,7 +75,13 @@ class SyncBatchNorm:
 
 
 class DataParallelTrainer:
-    def __init__(self, engine, process_group=None, n_buckets=3, sync_bn=False):
+    """native=True (the default on the nccl backend with the HIP engine; EAE_DP_NATIVE=0 switches it off): the gradient exchange
+    belongs to the ENGINE -- eae_dp_init joins an RCCL communicator of its own (the id travels over torch.distributed once) and
+    eae_ae_dp_train_step enqueues forward, backward, the bucketed all-reduce and Adam in one call, the decoder-side bucket overlapping
+    the encoder half of the backward (EAE_DP_OVERLAP=0: one all-reduce after the backward).  Otherwise -- gloo (the CPU tests), engines
+    without a C context -- the exchange goes through torch.distributed as before."""
+
+    def __init__(self, engine, process_group=None, n_buckets=3, sync_bn=False, native=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised (launch one process per GPU with torch.distributed.run)")
         self.eng = engine
@@ -85,6 +91,34 @@ class DataParallelTrainer:
         self.buckets = bucket_bounds(engine.poff, engine.poff[38], n_buckets)
         self._comm = None                      # high-priority stream the collectives are enqueued from (GPU engines only)
         self.sync_bn = SyncBatchNorm(engine, process_group) if (sync_bn and self.world > 1 and hasattr(engine, "ctx")) else None
+        self.native = False
+        if native is None:
+            native = os.environ.get("EAE_DP_NATIVE", "1") == "1"
+        if native and hasattr(engine, "ctx") and dist.get_backend(process_group) == "nccl":
+            self._init_native()
+
+    def _init_native(self):
+        import ctypes as C
+        from ._lib import check
+        eng = self.eng
+        if int(eng.lib.eae_dp_world(eng.ctx)) == self.world:       # the engine already belongs to a communicator of this size
+            self.native = True
+            return
+        idbuf = (C.c_ubyte * 128)()
+        t = torch.zeros(128, dtype=torch.uint8, device=eng.device)
+        if self.rank == 0:
+            check(eng.lib.eae_dp_unique_id(idbuf))
+            t.copy_(torch.tensor(list(idbuf), dtype=torch.uint8))
+        src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
+        dist.broadcast(t, src=src, group=self.pg)
+        raw = bytes(t.cpu().tolist())
+        with torch.cuda.device(eng.device):
+            check(eng.lib.eae_dp_init(eng.ctx, self.rank, self.world, raw))
+        self.native = True
+
+    def rccl_ranks(self):
+        """Ranks of the engine-owned RCCL communicator (0: the exchange goes through torch.distributed)."""
+        return int(self.eng.lib.eae_dp_world(self.eng.ctx)) if self.native else 0
 
     def broadcast_parameters(self, src=0):
         """Identical initial replicas: parameters, BatchNorm running stats and Adam state from rank `src`."""
@@ -118,6 +152,15 @@ class DataParallelTrainer:
             if hi != lo:
                 raise RuntimeError(f"SyncBatchNorm needs the same per-rank batch size on every rank (this step: {lo}..{hi}); pad or drop "
                                    "the short last batch (sampler with drop_last / padding), or train without sync_bn")
+        if self.native:
+            import ctypes as C
+            from ._lib import check
+            from .engine import _stream
+            io, keep = eng._io(x, labels, True, head, alpha)
+            overlap = 0 if os.environ.get("EAE_DP_OVERLAP", "1") == "0" else 1
+            with torch.cuda.device(eng.device):
+                check(eng.lib.eae_ae_dp_train_step(eng.ctx, _stream(), C.byref(io), float(lr), overlap))
+            return
         side = eng.side_stream() if hasattr(eng, "grad_step_begin") and hasattr(eng, "side_stream") else None
         if side is None:                       # engines without the split API (CPU stand-in of the gloo test)
             eng.grad_step(x, labels, alpha, head=head)

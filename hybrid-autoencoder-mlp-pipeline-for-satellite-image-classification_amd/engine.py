@@ -162,6 +162,11 @@ class AEEngine:
     def params_changed(self):
         check(self.lib.eae_params_changed(self.ctx))
 
+    def set_graph(self, on=True):
+        """Replay train_step from a captured hipGraph (one host call per step) instead of ~70 eager launches: for host-bound use,
+        i.e. several small configurations stepped concurrently (train.run_concurrent)."""
+        check(self.lib.eae_set_graph(self.ctx, int(bool(on))))
+
     def gate_timeouts(self):
         """0, or the progress value a side-stream gate gave up waiting for (diagnostic; synchronises the device)."""
         with torch.cuda.device(self.device):

@@ -20,17 +20,28 @@ from .modules import SupervisedAutoencoder, MLP
 class AEStepper:
     """HIP-engine stepper for SupervisedAutoencoder: train_step / eval_step / read_loss."""
 
-    def __init__(self, model, alpha, lr, head=True, max_batch=None):
+    def __init__(self, model, alpha, lr, head=True, max_batch=None, graph=None):
         from .engine import engine_for
         self.model, self.alpha, self.lr, self.head = model, float(alpha), float(lr), head
         self.eng = engine_for(model, max_batch=max_batch)
         self.eng.reset_optimizer()
+        if graph is not None:
+            self.eng.set_graph(graph)
+        self.graph = bool(graph)
+        self._stage = {}                     # graph replay: one fixed (imgs, labels) staging pair per batch size (a graph is keyed on its buffers)
         self.device = self.eng.device
 
     def begin(self):
         self.eng.reset_loss()
 
     def train_step(self, imgs, labels):
+        if self.graph:
+            b = int(imgs.shape[0])
+            if b not in self._stage:
+                self._stage[b] = (torch.empty_like(imgs), torch.empty_like(labels))
+            xs, ys = self._stage[b]
+            xs.copy_(imgs, non_blocking=True); ys.copy_(labels, non_blocking=True)
+            imgs, labels = xs, ys
         self.eng.train_step(imgs, labels, self.alpha, self.lr, head=self.head)
 
     def eval_step(self, imgs, labels):
@@ -74,7 +85,7 @@ def _first_batch_size(loader, default=64):
 
 # ------------------------------------------------------------------------------------------------ autoencoder
 def fit_autoencoder(train_loader, val_loader, alpha, lr, latent_dim=64, num_classes=10, num_epochs=80, patience=15,
-                    device="cuda", model=None, stepper=None, head=True, verbose=True, log=print):
+                    device="cuda", model=None, stepper=None, head=True, verbose=True, log=print, graph=None):
     """One (alpha, lr) configuration of the reference's AE loop (R.md:619-697).
 
     Returns dict(model, train_curve, val_curve, best_val_loss, epochs).  As in the reference, `model` holds the weights of
@@ -82,7 +93,7 @@ def fit_autoencoder(train_loader, val_loader, alpha, lr, latent_dim=64, num_clas
     if model is None and stepper is None:
         model = SupervisedAutoencoder(latent_dim=latent_dim, num_classes=num_classes).to(device)
     if stepper is None:
-        stepper = AEStepper(model, alpha, lr, head=head,
+        stepper = AEStepper(model, alpha, lr, head=head, graph=graph,
                             max_batch=max(_first_batch_size(train_loader), _first_batch_size(val_loader)))
     dev = getattr(stepper, "device", None)
     counter, best_val_loss = 0, float("inf")
@@ -168,8 +179,13 @@ def grid_search_autoencoder(train_loader, val_loader, alpha_values=(20, 25, 30, 
         def job_of(alpha, lr):
             def job():
                 lines = []
+                # (measured on MI355X at B=64, tools + bench.py `configs.grid_b64`: K = 4 / 8 / 16 eager configurations reach 1.6-1.7x the
+                #  single-configuration rate and then saturate at ~310 K kernel dispatches per second over all queues; hipGraph replay of
+                #  each step -- AEStepper(graph=True) -- removes the host from the loop and is SLOWER, 0.7-0.8x of eager: the limit is the
+                #  command processor's dependent-dispatch rate, i.e. the ~57 launches of a step, not the host)
+                extra = {}
                 r = fit_fn(train_loader, val_loader, alpha, lr, latent_dim=latent_dim, num_epochs=num_epochs, patience=patience,
-                           device=device, verbose=verbose, log=lines.append)
+                           device=device, verbose=verbose, log=lines.append, **extra)
                 r = dict(r)
                 # only the state_dict of a finished configuration is needed below: release its engine (workspace, streams) now
                 r["state"] = None if r.get("model") is None else {k: v.detach().cpu().clone() for k, v in r["model"].state_dict().items()}

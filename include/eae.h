@@ -79,6 +79,10 @@ int eae_bind(eae_ctx* ctx, float* params, float* grads, float* adam_m, float* ad
 long long eae_gate_timeouts(eae_ctx* ctx);
 long long eae_gate_timeouts_nosync(eae_ctx* ctx);   /* same word, no device synchronisation (the caller has synchronised its own stream) */
 int eae_gate_timeouts_clear(eae_ctx* ctx);
+/* Replay eae_ae_train_step from a captured hipGraph (from the third call with the same buffers, batch size and alpha) or enqueue it
+ * eagerly (default; EAE_GRAPH=1 in the environment turns replay on at creation).  Replay pays when the HOST is the limit: several small
+ * configurations stepped concurrently (train.py run_concurrent, R.md:599-711 at batch 64). */
+int eae_set_graph(eae_ctx* ctx, int on);
 /* The host changed parameter values (load_state_dict, optimizer outside the engine): repack before next use. */
 int eae_params_changed(eae_ctx* ctx);
 int eae_set_adam_step(eae_ctx* ctx, long long step);
@@ -127,6 +131,21 @@ void* eae_side_stream(eae_ctx* ctx);
  * disabled. */
 void* eae_dp_stream(eae_ctx* ctx, int which);
 int eae_adam_step_scaled(eae_ctx* ctx, void* stream, float lr, float weight_decay, float grad_scale);
+/* The collective owned by the engine (SURVEY.md 8b "DP eae_dp_init(ctx, rank, world, ncclUniqueId), eae_dp_allreduce_bucket"; new
+ * work: the reference has no parallelism).  One process per GPU; librccl is bound at run time (the copy already in the
+ * process if any).  eae_dp_unique_id: rank 0 draws the 128-byte ncclUniqueId, the caller ships it to the other ranks;
+ * eae_dp_init: every rank joins (collective call).  eae_dp_allreduce_bucket: in-place sum over the ranks of gradient-arena elements
+ * [elem_off, elem_off + count) on `stream`.  eae_dp_broadcast: `bytes` of a device buffer from `root` (identical replicas at start).
+ * eae_ae_dp_train_step: eae_ae_train_step for a replica -- forward, loss, backward, gradient all-reduce, Adam with the 1/world scale
+ * folded into the optimizer kernel -- enqueued by one call with no host code between backward and collective; overlap != 0 sends
+ * the decoder-side bucket (tensors 18..37) over the engine's hand-off stream while the encoder half of the backward computes. */
+int eae_dp_unique_id(void* id128);
+int eae_dp_init(eae_ctx* ctx, int rank, int world, const void* id128);
+int eae_dp_world(eae_ctx* ctx);
+int eae_dp_destroy(eae_ctx* ctx);
+int eae_dp_allreduce_bucket(eae_ctx* ctx, void* stream, long long elem_off, long long count);
+int eae_dp_broadcast(eae_ctx* ctx, void* stream, void* buf, long long bytes, int root);
+int eae_ae_dp_train_step(eae_ctx* ctx, void* stream, const eae_step_io* io, float lr, int overlap);
 /* Synchronized BatchNorm across data-parallel replicas (new work; SURVEY.md 8e: R ranks x B/R with SyncBN == 1 rank x B).
  * In train mode the engine calls `fn` once per BatchNorm layer in the forward (kind 0: `count` int64 fixed-point accumulators
  * starting at element `elem_offset` of acc_i64) and once per layer in the backward (kind 1: `count` fp64 sums at element

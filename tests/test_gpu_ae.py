@@ -452,16 +452,35 @@ def test_data_parallel_trainer_world1_rccl():
         created = True
     try:
         x, y = gu.make_images(8, 100)
-        ma, mb = _model(), _model()
-        ea, eb = _engine(ma), _engine(mb)
-        tr = dp.DataParallelTrainer(eb)
-        tr.broadcast_parameters()
+        xd, yd = _cuda(x), _cuda(y)
+        ma = _model()
+        ea = _engine(ma)
         for _ in range(2):
-            ea.train_step(_cuda(x), _cuda(y), 35.0, 5e-3)
-            tr.train_step(_cuda(x), _cuda(y), 35.0, 5e-3)
+            ea.train_step(xd, yd, 35.0, 5e-3)
         torch.cuda.synchronize()
-        assert torch.equal(ea.params, eb.params)
+        # (1) the engine-owned RCCL communicator (eae_dp_init / eae_ae_dp_train_step), overlapped and serial; (2) torch.distributed
+        for native, overlap in ((True, "1"), (True, "0"), (False, "0")):
+            os.environ["EAE_DP_OVERLAP"] = overlap
+            mb = _model()
+            eb = _engine(mb)
+            tr = dp.DataParallelTrainer(eb, native=native)
+            assert tr.native == native and tr.rccl_ranks() == (1 if native else 0)
+            tr.broadcast_parameters()
+            for _ in range(2):
+                tr.train_step(xd, yd, 35.0, 5e-3)
+            torch.cuda.synchronize()
+            assert eb.gate_timeouts() == 0
+            assert torch.equal(ea.params, eb.params), (native, overlap)
+            assert torch.equal(ea.adam_m, eb.adam_m) and torch.equal(ea.bn_running, eb.bn_running)
+            if native:       # the bucket entry point by itself: a 1-rank sum leaves the arena untouched
+                from eae_amd._lib import check
+                import gpu_util as G
+                g0 = eb.grads.clone()
+                check(eb.lib.eae_dp_allreduce_bucket(eb.ctx, G.stream(), eb.poff[18], eb.poff[38] - eb.poff[18]))
+                torch.cuda.synchronize()
+                assert torch.equal(g0, eb.grads)
     finally:
+        os.environ.pop("EAE_DP_OVERLAP", None)
         if created:
             dist.destroy_process_group()
 
@@ -853,7 +872,7 @@ def _stall(seconds):
 def test_caller_stream_stalled_for_seconds_in_front_of_a_step_is_waited_for():
     """the side-stream gates used to give up after ~2 s and let the weight-gradient kernels run before the kernels
     they depend on.  The spin is now bounded by 30 s of wall clock: a step enqueued behind a 2.6 s stall of the caller's stream
-    (a late data-parallel peer, a long copy) produces the same gradients, bit for bit, as an unstalled one."""
+    (a late data-parallel peer, a long copy; > 2 s, the old bound) produces the same gradients, bit for bit, as an unstalled one."""
     x, y = gu.make_images(8, 321)
     ma, mb = _model(), _model()
     ea, eb = _engine(ma), _engine(mb)
@@ -862,11 +881,11 @@ def test_caller_stream_stalled_for_seconds_in_front_of_a_step_is_waited_for():
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _stall(2.6)
+    _stall(3.0)
     eb.grad_step(xd, yd, 35.0)
     e1.record()
     torch.cuda.synchronize()
-    assert e0.elapsed_time(e1) > 2300.0     # the step really was enqueued behind the stall
+    assert e0.elapsed_time(e1) > 2100.0     # the step really was enqueued behind a stall longer than the old 2 s bound
     assert eb.gate_timeouts() == 0
     assert torch.equal(ea.grads, eb.grads)
 

@@ -68,6 +68,7 @@ if prof:
         subprocess.run(["cp", f[0], out])
         tr = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)
         if tr:
+            subprocess.run(["cp", tr[0], os.path.join(ROOT, "gpurun_out", f"ab_trace_{n}.csv")])
             tl = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "timeline.py"), tr[0]], capture_output=True, text=True).stdout
             open(os.path.join(ROOT, "gpurun_out", f"ab_timeline_{n}.txt"), "w").write(tl)
     names = sorted(set().union(*[set(t) for t in tabs.values()]), key=lambda k: -max(t.get(k, (0, 0))[0] * t.get(k, (0, 0))[1] for t in tabs.values()))
