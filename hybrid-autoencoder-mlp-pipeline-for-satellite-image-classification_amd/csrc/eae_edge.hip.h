@@ -25,47 +25,89 @@ constexpr int E_PATCH = E_PH * E_PW * 4;           // bf16 elements ([row][col][
 constexpr int E_AT = 128 * PIX_STRIDE;             // im2col tile [128][32 + pad]
 
 // Stage the 3-channel patch (rows iy0.., cols ix0..) as bf16 [E_PH][E_PW][4] with zero padding outside the image.
+// Every pixel of the patch is written exactly once, as a whole 8-byte [c0, c1, c2, 0] pixel: a thread takes 4 consecutive pixels of
+// a row -- for the planar fp32 source one float4 per colour plane -- and writes them with four 8-byte stores (the patch starts one
+// pixel left of a 16-byte boundary: the halo column).  Round 2 cleared the patch, synchronised, and scattered 2-byte elements plane
+// by plane (12 ds_write_b16 per float4 triple): by the stamps 4.8-8.5 K of conv1's 9.5-14.6 K workgroup cycles.  One barrier, at the end.
+// (split into a load and a write half so that a loop over tiles can keep the NEXT tile's raw values in flight: edge_wgrad_kernel)
+template <int SRC3> struct Patch3Regs { float4 v[3]; };                 // planar fp32: one float4 per colour plane (halo threads: .x only)
+template <> struct Patch3Regs<1> { uint4 v[2]; };                      // bf16 NHWC4: up to two 16-byte pieces per thread
 template <int SRC3>
-__device__ __forceinline__ void stage_patch3(const void* src, bf16_t* p3, int n, int H, int W, int iy0, int ix0) {
+__device__ __forceinline__ void patch3_load(const void* src, int n, int H, int W, int iy0, int ix0, Patch3Regs<SRC3>& r) {
   const int tid = threadIdx.x;
-  for (int i = tid; i < E_PH * E_PW; i += 256) {     // clear channel 3 and the borders
-    *reinterpret_cast<uint2*>(p3 + i * 4) = make_uint2(0, 0);
-  }
-  __syncthreads();
-  if (SRC3 == SRC3_NCHW_F32) {
+  if constexpr (SRC3 == SRC3_NCHW_F32) {
     const float* x = static_cast<const float*>(src);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r.v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     // interior columns ix0+1 .. ix0+64 are image columns (ix0 = 2*tx0-1, tx0 multiple of 32 -> 16-byte aligned rows)
-    for (int i = tid; i < 3 * E_PH * 16; i += 256) {
-      int c4 = i % 16, r = (i / 16) % E_PH, c = i / (16 * E_PH);
-      int iy = iy0 + r, ix = ix0 + 1 + c4 * 4;
-      if (iy < 0 || iy >= H) continue;
-      float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * 3 + c) * H + iy) * W + ix);
-      bf16_t* d = p3 + (r * E_PW + 1 + c4 * 4) * 4 + c;
-      d[0] = (bf16_t)f2bf(v.x); d[4] = (bf16_t)f2bf(v.y); d[8] = (bf16_t)f2bf(v.z); d[12] = (bf16_t)f2bf(v.w);
-    }
-    if (ix0 >= 0)                                        // left halo column is a real pixel for tiles not at the image edge
-      for (int i = tid; i < 3 * E_PH; i += 256) {
-        int r = i % E_PH, c = i / E_PH, iy = iy0 + r;
-        if (iy >= 0 && iy < H) p3[(r * E_PW) * 4 + c] = (bf16_t)f2bf(x[(((size_t)n * 3 + c) * H + iy) * W + ix0]);
+    if (tid < E_PH * 16) {
+      const int c4 = tid & 15, rr = tid >> 4;
+      const int iy = iy0 + rr, ix = ix0 + 1 + c4 * 4;
+      if (iy >= 0 && iy < H) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r.v[c] = *reinterpret_cast<const float4*>(x + (((size_t)n * 3 + c) * H + iy) * W + ix);
       }
+    } else if (tid < E_PH * 16 + E_PH) {          // left halo column: a real pixel for tiles not at the image edge, else zero padding
+      const int iy = iy0 + tid - E_PH * 16;
+      if (ix0 >= 0 && iy >= 0 && iy < H) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r.v[c].x = x[(((size_t)n * 3 + c) * H + iy) * W + ix0];
+      }
+    }
   } else {
     const bf16_t* g = static_cast<const bf16_t*>(src);
-    for (int i = tid; i < E_PH * 32; i += 256) {       // 2 pixels (16 B) per piece
-      int c2 = i % 32, r = i / 32;
-      int iy = iy0 + r, ix = ix0 + 1 + c2 * 2;
-      if (iy < 0 || iy >= H) continue;
-      uint4 v = *reinterpret_cast<const uint4*>(g + (((size_t)n * H + iy) * W + ix) * 4);
-      bf16_t* d = p3 + (r * E_PW + 1 + c2 * 2) * 4;
-      *reinterpret_cast<uint2*>(d) = make_uint2(v.x, v.y);
-      *reinterpret_cast<uint2*>(d + 4) = make_uint2(v.z, v.w);
-    }
-    if (ix0 >= 0)
-      for (int r = tid; r < E_PH; r += 256) {
-        int iy = iy0 + r;
-        if (iy >= 0 && iy < H)
-          *reinterpret_cast<uint2*>(p3 + (r * E_PW) * 4) = *reinterpret_cast<const uint2*>(g + (((size_t)n * H + iy) * W + ix0) * 4);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + k * 256;
+      r.v[k] = make_uint4(0, 0, 0, 0);
+      if (i < E_PH * 32) {                        // 2 pixels (16 B) per piece
+        const int c2 = i & 31, rr = i >> 5;
+        const int iy = iy0 + rr, ix = ix0 + 1 + c2 * 2;
+        if (iy >= 0 && iy < H) r.v[k] = *reinterpret_cast<const uint4*>(g + (((size_t)n * H + iy) * W + ix) * 4);
+      } else if (i < E_PH * 32 + E_PH) {          // the halo column
+        const int iy = iy0 + i - E_PH * 32;
+        if (ix0 >= 0 && iy >= 0 && iy < H) {
+          const uint2 h = *reinterpret_cast<const uint2*>(g + (((size_t)n * H + iy) * W + ix0) * 4);
+          r.v[k].x = h.x; r.v[k].y = h.y;
+        }
       }
+    }
   }
+}
+template <int SRC3>
+__device__ __forceinline__ void patch3_write(bf16_t* p3, const Patch3Regs<SRC3>& r) {
+  const int tid = threadIdx.x;
+  if constexpr (SRC3 == SRC3_NCHW_F32) {
+    if (tid < E_PH * 16) {
+      const int c4 = tid & 15, rr = tid >> 4;
+      uint2* d = reinterpret_cast<uint2*>(p3 + (rr * E_PW + 1 + c4 * 4) * 4);
+      d[0] = make_uint2(pack2(r.v[0].x, r.v[1].x), f2bf(r.v[2].x));
+      d[1] = make_uint2(pack2(r.v[0].y, r.v[1].y), f2bf(r.v[2].y));
+      d[2] = make_uint2(pack2(r.v[0].z, r.v[1].z), f2bf(r.v[2].z));
+      d[3] = make_uint2(pack2(r.v[0].w, r.v[1].w), f2bf(r.v[2].w));
+    } else if (tid < E_PH * 16 + E_PH) {
+      *reinterpret_cast<uint2*>(p3 + ((tid - E_PH * 16) * E_PW) * 4) = make_uint2(pack2(r.v[0].x, r.v[1].x), f2bf(r.v[2].x));
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + k * 256;
+      if (i < E_PH * 32) {
+        const int c2 = i & 31, rr = i >> 5;
+        uint2* d = reinterpret_cast<uint2*>(p3 + (rr * E_PW + 1 + c2 * 2) * 4);
+        d[0] = make_uint2(r.v[k].x, r.v[k].y);
+        d[1] = make_uint2(r.v[k].z, r.v[k].w);
+      } else if (i < E_PH * 32 + E_PH) {
+        *reinterpret_cast<uint2*>(p3 + ((i - E_PH * 32) * E_PW) * 4) = make_uint2(r.v[k].x, r.v[k].y);
+      }
+    }
+  }
+}
+template <int SRC3>
+__device__ __forceinline__ void stage_patch3(const void* src, bf16_t* p3, int n, int H, int W, int iy0, int ix0) {
+  Patch3Regs<SRC3> r;
+  patch3_load<SRC3>(src, n, H, W, iy0, ix0, r);
+  patch3_write<SRC3>(p3, r);
   __syncthreads();
 }
 
@@ -224,15 +266,18 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(EdgeWgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-  for (int ti = 0; ti < a.tiles_per_block; ++ti) {
-    int t = blockIdx.x * a.tiles_per_block + ti;
-    if (t >= a.ntiles) break;
+  // Tile loop with the NEXT tile's raw values (side pieces + 3-channel patch) requested before this tile is multiplied: round 2
+  // loaded, staged and multiplied one tile after the other, every tile exposing a memory round trip (conv1's weight gradient is the
+  // last kernel of the backward: 32 us on the critical path).
+  const int t_begin = blockIdx.x * a.tiles_per_block;
+  int t_end = t_begin + a.tiles_per_block;
+  if (t_end > a.ntiles) t_end = a.ntiles;
+  RawPiece<SMODE> raw[2];
+  Patch3Regs<SRC3> pr;
+  auto request = [&](int t) __attribute__((always_inline)) {
     const int txb = t % tiles_x; t /= tiles_x;
     const int tyb = t % tiles_y; t /= tiles_y;
     const int n = t;
-    __syncthreads();
-    // side tile [128][32] with transform
-    RawPiece<SMODE> raw[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int m = (tid + i * 256) >> 2;
@@ -240,12 +285,22 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(EdgeWgradArgs a) {
       size_t off = ((((size_t)n * Hout + tyb * E_TH + ty) * Wout) + txb * E_TW + tx) * 32 + kgs * 8;
       load_piece<SMODE>(a.side, off, true, raw[i]);
     }
-    stage_patch3<SRC3>(a.src3, p3, n, a.H, a.W, 2 * tyb * E_TH - 1, 2 * txb * E_TW - 1);
+    patch3_load<SRC3>(a.src3, n, a.H, a.W, 2 * tyb * E_TH - 1, 2 * txb * E_TW - 1, pr);
+  };
+  if (t_begin < t_end) request(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();                 // the previous tile's fragment reads (at, st) and im2col reads (p3) are done
+    patch3_write<SRC3>(p3, pr);
+    uint4 sv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) sv[i] = transform_piece<SMODE>(raw[i], true, cc);
+    if (t + 1 < t_end) request(t + 1);
+    __syncthreads();                 // the 3-channel patch is complete
     build_im2col27(p3, at);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int m = (tid + i * 256) >> 2;
-      *reinterpret_cast<uint4*>(st + m * PIX_STRIDE + kgs * 8) = transform_piece<SMODE>(raw[i], true, cc);
+      *reinterpret_cast<uint4*>(st + m * PIX_STRIDE + kgs * 8) = sv[i];
     }
     __syncthreads();
     // wave w reduces pixels 32w .. 32w+31
@@ -309,12 +364,10 @@ template <int SRC>
 __global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
   constexpr int PH = E_TH + 1, PW = E_TW + 1, NPIX = PH * PW;       // 5 x 33 input pixels
   constexpr int NPA = (NPIX * 4 + 255) / 256;
-  // the pre-sigmoid tile `sl` (8.7 KB) and the gradient tile `gl` (4 KB) reuse the patch (13.2 KB) once every wave has read its
-  // fragments: 26.5 -> 13.8 KB of LDS per block, 8 instead of 6 blocks per CU
+  // the pre-sigmoid tile `sl` (8.7 KB) reuses the patch (13.2 KB) once every wave has read its fragments: 8 blocks per CU
   __shared__ __attribute__((aligned(16))) bf16_t patch[NPIX * PIX_STRIDE];
-  static_assert(sizeof(bf16_t) * NPIX * PIX_STRIDE >= sizeof(float) * 128 * 17 + 16 + sizeof(bf16_t) * 8 * 64 * 4, "tiles must fit the patch");
+  static_assert(sizeof(bf16_t) * NPIX * PIX_STRIDE >= sizeof(float) * 128 * 17, "the tile must fit the patch");
   float* const sl = reinterpret_cast<float*>(patch);
-  bf16_t* const gl = patch + (128 * 17 * 2 + 8);       // behind sl, 16-byte aligned
   __shared__ float redl[4][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Hout = a.Hin * 2, Wout = a.Win * 2;
@@ -382,28 +435,44 @@ __global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
     for (int r = 0; r < 4; ++r) sl[((wave * 2 + mi) * 16 + (lane >> 4) * 4 + r) * 17 + (lane & 15)] = acc[mi][r];
   __syncthreads();
   EDGE_STAMP(5);
-  // elementwise pass in NCHW order: e -> (co, oy, ox) over the 8 x 64 x 3 output tile
+  // Elementwise pass, one thread per OUTPUT PIXEL (2 pixels per thread: oy = tid / 64 + 4 i, ox = tid % 64), all three channels: the
+  // target / x_hat accesses stay coalesced per plane (a wave = one 64-pixel row segment of a plane), and the gradient pixel
+  // [g0, g1, g2, 0] leaves as ONE 8-byte NHWC4 store.  (Round 2 went element by element in NCHW order -- 6 elements per thread, each
+  // with its own 64-bit address arithmetic -- and staged the gradient tile through LDS with 2-byte scatter writes, a clear and two
+  // more barriers: by the stamps this phase was 7.7-12 K of a workgroup's 23-38 K cycles, all of it VALU issue at 8 workgroups per CU.)
   float lsum = 0.f, gsum[3] = {0.f, 0.f, 0.f};
-  if (a.g4) *reinterpret_cast<uint4*>(gl + tid * 8) = make_uint4(0, 0, 0, 0);   // clears [8*64*4] bf16 = 4 KB
-  __syncthreads();
+  const float b0 = a.bias[0], b1 = a.bias[1], b2 = a.bias[2];
+  const size_t plane = (size_t)Hout * Wout;
+  const int ox = tid & 63;
+  float xt[2][3];                    // the six target values of this thread, requested together (the stores below may not be reordered against loads)
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    int e = tid + i * 256;
-    int ox = e & 63, oy = (e >> 6) & 7, co = e >> 9;
-    int pos = (oy >> 1) * E_TW + (ox >> 1), ph = (oy & 1) * 2 + (ox & 1);
-    float s = sl[pos * 17 + ph * 3 + co] + a.bias[co];
-    float xh = 1.0f / (1.0f + __expf(-s));
-    size_t gi = (((size_t)n * 3 + co) * Hout + (2 * iy0 + oy)) * Wout + 2 * ix0 + ox;
-    if (a.x_hat) a.x_hat[gi] = xh;
-    if (a.x) {
-      float d = xh - a.x[gi];
-      lsum = fmaf(d, d, lsum);
-      if (a.g4) {
-        uint32_t gb = f2bf(a.gscale * d * xh * (1.0f - xh));
-        gl[(oy * 64 + ox) * 4 + co] = (bf16_t)gb;
-        gsum[i >> 1] += bf2f(gb);
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int co = 0; co < 3; ++co)
+      xt[i][co] = a.x ? a.x[((size_t)n * 3 + co) * plane + (size_t)(2 * iy0 + (tid >> 6) + 4 * i) * Wout + 2 * ix0 + ox] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int oy = (tid >> 6) + 4 * i;
+    const int pos = (oy >> 1) * E_TW + (ox >> 1), ph = (oy & 1) * 2 + (ox & 1);
+    const float* sp = sl + pos * 17 + ph * 3;
+    const float s3[3] = {sp[0] + b0, sp[1] + b1, sp[2] + b2};
+    const size_t pix = (size_t)(2 * iy0 + oy) * Wout + 2 * ix0 + ox;
+    const size_t gi = (size_t)n * 3 * plane + pix;
+    uint32_t gb[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+      const float xh = 1.0f / (1.0f + __expf(-s3[co]));
+      if (a.x_hat) a.x_hat[gi + co * plane] = xh;
+      if (a.x) {
+        const float d = xh - xt[i][co];
+        lsum = fmaf(d, d, lsum);
+        if (a.g4) {
+          gb[co] = f2bf(a.gscale * d * xh * (1.0f - xh));
+          gsum[co] += bf2f(gb[co]);
+        }
       }
     }
+    if (a.g4) *reinterpret_cast<uint2*>(a.g4 + ((size_t)n * plane + pix) * 4) = make_uint2(gb[0] | (gb[1] << 16), gb[2]);
   }
   EDGE_STAMP(6);
   if (a.loss_part) {
@@ -414,13 +483,8 @@ __global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
       for (int o = 32; o >= 1; o >>= 1) v[k] += __shfl_xor(v[k], o);
       if (lane == 0) redl[wave][k] = v[k];
     }
-  }
-  __syncthreads();
-  if (a.loss_part && tid < 4) a.loss_part[(size_t)blockIdx.x * 4 + tid] = redl[0][tid] + redl[1][tid] + redl[2][tid] + redl[3][tid];
-  if (a.g4) {
-    int row = tid >> 5, c2 = tid & 31;     // 8 rows x 32 pieces of 2 pixels
-    uint4 v = *reinterpret_cast<const uint4*>(gl + (row * 64 + c2 * 2) * 4);
-    *reinterpret_cast<uint4*>(a.g4 + (((size_t)n * Hout + 2 * iy0 + row) * Wout + 2 * ix0 + c2 * 2) * 4) = v;
+    __syncthreads();
+    if (tid < 4) a.loss_part[(size_t)blockIdx.x * 4 + tid] = redl[0][tid] + redl[1][tid] + redl[2][tid] + redl[3][tid];
   }
   EDGE_STAMP(7);
 }

@@ -187,31 +187,36 @@ struct FcTnArgs {
 // raw 16-byte piece of 8 consecutive operand elements as it comes back from memory (fp32 sources: two float4), and its transform
 template <int MODE> struct FcRaw { uint4 v; };
 template <> struct FcRaw<SRC_F32> { float4 lo, hi; };
+// `off` must be in range for every thread (callers clamp the row of out-of-range threads): the load is UNCONDITIONAL -- a load under a
+// per-thread condition makes hipcc branch around it and drain the whole vector-memory queue (s_waitcnt vmcnt(0)) at the join, which
+// serialises a prefetch ring; out-of-range rows are zeroed by fc_finish_raw instead
 template <int MODE>
-__device__ __forceinline__ void fc_load_raw(const SrcDesc& s, size_t off, bool valid, FcRaw<MODE>& r) {
+__device__ __forceinline__ void fc_load_raw(const SrcDesc& s, size_t off, FcRaw<MODE>& r) {
   if constexpr (MODE == SRC_F32) {
     const float* f = reinterpret_cast<const float*>(s.p0) + off;
-    r.lo = valid ? *reinterpret_cast<const float4*>(f) : make_float4(0.f, 0.f, 0.f, 0.f);
-    r.hi = valid ? *reinterpret_cast<const float4*>(f + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    r.lo = *reinterpret_cast<const float4*>(f);
+    r.hi = *reinterpret_cast<const float4*>(f + 4);
   } else {
-    r.v = valid ? *reinterpret_cast<const uint4*>(s.p0 + off) : make_uint4(0, 0, 0, 0);
+    r.v = *reinterpret_cast<const uint4*>(s.p0 + off);
   }
 }
 template <int MODE>
 __device__ __forceinline__ uint4 fc_finish_raw(const FcRaw<MODE>& r, bool valid, const float* cs, const float* ct) {
+  const uint32_t m = valid ? 0xffffffffu : 0u;
+  uint4 o;
   if constexpr (MODE == SRC_F32) {
     float v[8] = {r.lo.x, r.lo.y, r.lo.z, r.lo.w, r.hi.x, r.hi.y, r.hi.z, r.hi.w};
-    return pack8(v);
+    o = pack8(v);
   } else if constexpr (MODE == SRC_BNRELU) {
-    if (!valid) return make_uint4(0, 0, 0, 0);
     float x[8];
     unpack8(r.v, x);
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = fmaxf(fmaf(cs[j], x[j], ct[j]), 0.f);
-    return pack8(x);
+    o = pack8(x);
   } else {
-    return r.v;
+    o = r.v;
   }
+  return make_uint4(o.x & m, o.y & m, o.z & m, o.w & m);
 }
 
 // The reduction runs over the batch in chunks of 64 rows; one block walks ALL chunks, so its time used to be (number of chunks) x
@@ -245,18 +250,18 @@ __global__ __launch_bounds__(256) void fc_tn_kernel(FcTnArgs a) {
   const int nchunks = (a.Bt + 63) / 64;
   FcRaw<PMODE> rp[FC_TN_D][2];
   FcRaw<QMODE> rq[FC_TN_D][2];
-  auto issue = [&](FcRaw<PMODE> (&xp)[2], FcRaw<QMODE> (&xq)[2], int b0) __attribute__((always_inline)) {
+  auto issue = [&](FcRaw<PMODE> (&xp)[2], FcRaw<QMODE> (&xq)[2], int c) __attribute__((always_inline)) {
+    const int b0 = (c < nchunks ? c : nchunks - 1) * 64;         // (past the end: the last chunk again, never consumed)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int row = (tid + i * 256) >> 3;
-      const bool v = (b0 + row) < a.Bt;
-      fc_load_raw<PMODE>(a.p, (size_t)(b0 + row) * a.I + i0 + kg8 * 8, v, xp[i]);
-      fc_load_raw<QMODE>(a.q, (size_t)(b0 + row) * a.J + j0 + kg8 * 8, v, xq[i]);
+      int row = b0 + ((tid + i * 256) >> 3);
+      row = row < a.Bt ? row : a.Bt - 1;                          // clamped: the load is unconditional, the value is zeroed in fc_finish_raw
+      fc_load_raw<PMODE>(a.p, (size_t)row * a.I + i0 + kg8 * 8, xp[i]);
+      fc_load_raw<QMODE>(a.q, (size_t)row * a.J + j0 + kg8 * 8, xq[i]);
     }
   };
 #pragma unroll
-  for (int d = 0; d < FC_TN_D; ++d)
-    if (d < nchunks) issue(rp[d], rq[d], d * 64);
+  for (int d = 0; d < FC_TN_D; ++d) issue(rp[d], rq[d], d);
   for (int c0 = 0; c0 < nchunks; c0 += FC_TN_D) {
 #pragma unroll
     for (int d = 0; d < FC_TN_D; ++d) {
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void fc_tn_kernel(FcTnArgs a) {
         *reinterpret_cast<uint4*>(pl + row * FC_LS + kg8 * 8) = pv;
         *reinterpret_cast<uint4*>(ql + row * FC_LS + kg8 * 8) = qv;
       }
-      if (c + FC_TN_D < nchunks) issue(rp[d], rq[d], (c + FC_TN_D) * 64);
+      issue(rp[d], rq[d], c + FC_TN_D);            // unconditional (clamped): no branch around loads inside the ring
       __syncthreads();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {

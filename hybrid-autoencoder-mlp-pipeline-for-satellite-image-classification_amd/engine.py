@@ -458,7 +458,6 @@ class _HalfFunction(torch.autograd.Function):
 
 def _half_forward(module, inp, half):
     eng = engine_for(module)
-    eng.params_changed()
     slots = [p for p, i in eng._slots if (i < 18 if half == "enc" else 18 <= i < 34)]
     grad_mode = torch.is_grad_enabled()
     if grad_mode and half == "enc" and inp.requires_grad:
@@ -472,6 +471,7 @@ def _half_forward(module, inp, half):
         raise RuntimeError("Decoder.forward on the decoder of the SupervisedAutoencoder whose encoder forward is awaiting its backward: the "
                            "two halves share one engine; call model(x) (x_hat, logits, z = model(x)), or use stand-alone Encoder / Decoder "
                            "modules for a hand-composed dec(enc(x))")
+    eng.params_changed()           # (after the guards: it drops whatever forward is resident in the engine)
     if grad_mode and (inp.requires_grad or any(p.requires_grad for p in slots)):
         return _HalfFunction.apply(eng, half, bool(module.training), inp, *slots)
     return eng.encoder(inp, train=module.training) if half == "enc" else eng.decoder(inp, train=module.training)

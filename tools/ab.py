@@ -2,7 +2,7 @@
 """A/B of library variants on ONE box (boxes differ by up to 7 %): interleaved bench.py runs per variant, then (--prof) one
 rocprofv3 --kernel-trace --stats pass per variant with the per-kernel average durations side by side.
 
-    tools/ab.py [--prof] [--rounds 3] [--steps 300] [--batch 512] name=path/to/libeae_x.so[,ENV=VAL...] ...
+    tools/ab.py [--prof] [--rounds 3] [--steps 300] [--batch 512] name=path/to/libeae_x.so[;ENV=VAL...] ...
 
 `path` may be "-" for the product library.  Diagnostic tool (GPU box)."""
 import csv
@@ -33,7 +33,7 @@ rounds, steps, batch = int(opt("--rounds", 3)), opt("--steps", "300"), opt("--ba
 variants = []
 for a in args:
     name, rest = a.split("=", 1)
-    parts = rest.split(",")
+    parts = rest.split(";")
     env = dict(p.split("=", 1) for p in parts[1:])
     if parts[0] != "-":
         env["EAE_LIB_PATH"] = os.path.abspath(parts[0])
