@@ -32,6 +32,7 @@ BYTES_PER_IMG_BF16 = 1.354e6
 BYTES_PER_STEP_WEIGHTS = 44.7e6
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense fp8
 
 
 def make_batch(b, device, seed):
@@ -98,12 +99,12 @@ def cpu_baseline(seconds_budget=10.0):
             "legs": legs}
 
 
-def kernel_roofline(eng, step_fn, batch):
-    """Per-launch duration of the DOMINANT kernel -- the one with the largest total duration in the newest committed rocprofv3
-    summary under profiles/ -- measured live with HIP events on the stream it is launched on inside real train steps, priced
-    against its bounding roofline with its own ALGORITHMIC bytes."""
+def kernel_roofline(eng, step_fn, batch, tag="b512", H=64, W=64, mfma_peak=None, steps=32):
+    """Per-launch duration of the DOMINANT kernel of a workload -- the one with the largest total duration in the newest committed
+    rocprofv3 summary of that workload under profiles/ -- measured live with HIP events on the stream it is launched on inside real
+    train steps, priced against its bounding roofline with its own ALGORITHMIC bytes."""
     from eae_amd import profile_hooks as PH
-    return PH.dominant_kernel_roofline(eng, step_fn, batch, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFLOPS)
+    return PH.dominant_kernel_roofline(eng, step_fn, batch, HBM_PEAK_GBS, mfma_peak or MFMA_BF16_PEAK_TFLOPS, steps=steps, tag=tag, H=H, W=W)
 
 
 def time_steps(fn, steps, warmup):
@@ -117,26 +118,40 @@ def time_steps(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
-def config5_leg(batch=128, steps=20, warmup=5):
+C5_WORKLOAD = ("BASELINE configs[4], one GPU's share: 256x256x3 inputs, 256-d latent, joint train step; fp8 = e4m3 weights / "
+               "activations, e5m2 gradients on v_mfma_f32_16x16x32_{fp8,bf8}_{fp8,bf8} for the six 3x3 layers (delayed scaling), "
+               "bf16 = the same shape through the bf16 kernels")
+
+
+def config5_engine(quant, batch=128):
     import eae_amd
     from eae_amd.engine import AEEngine
-    res = {"workload": "BASELINE configs[4], one GPU's share: 256x256x3 inputs, 256-d latent, joint train step; fp8 = e4m3 weights / "
-                       "activations, e5m2 gradients on v_mfma_f32_16x16x32_{fp8,bf8}_{fp8,bf8} for the six 3x3 layers (delayed scaling), "
-                       "bf16 = the same shape through the bf16 kernels", "per_gpu_batch": batch}
     g = torch.Generator(device="cuda")
     g.manual_seed(4321)
     x = torch.rand((batch, 3, 256, 256), generator=g, device="cuda")
     y = torch.randint(0, 10, (batch,), generator=g, device="cuda")
+    torch.manual_seed(0)
+    m = eae_amd.SupervisedAutoencoder(latent_dim=256, num_classes=10, image_size=256).cuda().train()
+    eng = AEEngine(m, max_batch=batch, quant=quant)
+    if quant == "fp8":
+        eng.fp8_calibrate(x, y, ALPHA)
+    return m, eng, (lambda: eng.train_step(x, y, ALPHA, LR))
+
+
+def config5_leg(batch=128, steps=20, warmup=5, roofline=True):
+    res = {"workload": C5_WORKLOAD, "per_gpu_batch": batch}
     for quant in ("fp8", "bf16"):
-        torch.manual_seed(0)
-        m = eae_amd.SupervisedAutoencoder(latent_dim=256, num_classes=10, image_size=256).cuda().train()
-        eng = AEEngine(m, max_batch=batch, quant=quant)
-        if quant == "fp8":
-            eng.fp8_calibrate(x, y, ALPHA)
-        sec = time_steps(lambda: eng.train_step(x, y, ALPHA, LR), steps, warmup)
+        m, eng, step = config5_engine(quant, batch)
+        sec = time_steps(step, steps, warmup)
         res[quant] = {"ms_per_step": round(1e3 * sec, 3), "images_per_s": round(batch / sec, 1),
                       "final_loss": round(float(eng.loss_last.cpu()[0]), 4)}
-        del eng, m
+        if roofline:
+            try:
+                res[quant]["roofline"] = kernel_roofline(eng, step, batch, tag=f"c5{quant}", H=256, W=256, steps=12,
+                                                         mfma_peak=MFMA_FP8_PEAK_TFLOPS if quant == "fp8" else MFMA_BF16_PEAK_TFLOPS)
+            except Exception as e:
+                res[quant]["roofline"] = {"error": str(e)[:200]}
+        del eng, m, step
         torch.cuda.empty_cache()
     return res
 
@@ -183,6 +198,45 @@ def grid_b64_leg(k=int(os.environ.get("EAE_GRID_K", "4")), steps=150, warmup=15)
     return res
 
 
+C2_WORKLOAD = "BASELINE configs[1]: batch 256, encoder+decoder reconstruction (MSE) only, bf16"
+
+
+def side_workload(args, device):
+    """`--workload c2 | c5fp8 | c5bf16`: the SAME timed loop over one of the other single-GPU BASELINE configurations, so that
+    tools/profile_round.sh can put rocprofv3 around it (kernel stats + PMC passes per workload) and the line carries its roofline."""
+    import eae_amd
+    from eae_amd.engine import engine_for
+    if args.workload == "c2":
+        batch = 256 if args.batch == BATCH else args.batch
+        torch.manual_seed(0)
+        model = eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=10).to(device)
+        eng = engine_for(model, max_batch=batch)
+        x, y = make_batch(batch, device, seed=1234)
+        step = lambda: eng.train_step(x, y, 1.0, LR, head=False)
+        desc, tag, hw, dtype, peak = C2_WORKLOAD, "c2", 64, "bf16", MFMA_BF16_PEAK_TFLOPS
+    else:
+        quant = args.workload[2:]
+        batch = 128 if args.batch == BATCH else args.batch
+        model, eng, step = config5_engine(quant, batch)
+        desc, tag, hw, dtype = C5_WORKLOAD + f" [{quant} leg]", f"c5{quant}", 256, quant
+        peak = MFMA_FP8_PEAK_TFLOPS if quant == "fp8" else MFMA_BF16_PEAK_TFLOPS
+    sec = time_steps(step, args.steps, args.warmup)
+    loss = float(eng.loss_last[0].item())
+    if not np.isfinite(loss) or eng.gate_timeouts():
+        raise SystemExit("non-finite loss or a gate time-out in the timed region")
+    out = {"metric": "EuroSAT 64x64 RGB images/sec (AE+MLP train step)", "value": round(batch / sec, 1), "unit": "images/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * sec, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+           "config": {"workload": desc, "per_gpu_batch": batch, "global_batch": batch, "parallelism": "single", "final_loss": round(loss, 4),
+                      "note": "NOT the headline configuration (that is the default run, configs[2]); images are %dx%d here" % (hw, hw)}}
+    if not args.no_roofline:
+        try:
+            out["roofline"] = kernel_roofline(eng, step, batch, tag=tag, H=hw, W=hw, mfma_peak=peak, steps=32 if hw == 64 else 12)
+        except Exception as e:
+            out["roofline"] = {"error": str(e)[:200]}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +246,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configs[1] measurement")
+    ap.add_argument("--workload", choices=("c3", "c2", "c5fp8", "c5bf16"), default="c3",
+                    help="c3 = BASELINE configs[2], the headline (default); the others run the same loop over configs[1] / configs[4]'s shape")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -205,6 +261,11 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the measured path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+
+    if args.workload != "c3":
+        if world > 1:
+            raise SystemExit("--workload other than c3 is a single-GPU measurement")
+        return side_workload(args, device)
 
     import eae_amd
     from eae_amd.engine import engine_for
@@ -296,16 +357,18 @@ def main():
                 x2, y2 = x[:256].contiguous(), y[:256].contiguous()
                 sec = time_steps(lambda: eng.train_step(x2, y2, 1.0, LR, head=False), min(args.steps, 200), min(args.warmup, 20))
                 b2 = 256 * (BYTES_PER_IMG_BF16 - 0.0) + BYTES_PER_STEP_WEIGHTS
-                out["configs"] = {"c2": {"workload": "BASELINE configs[1]: batch 256, encoder+decoder reconstruction (MSE) only, bf16",
+                out["configs"] = {"c2": {"workload": C2_WORKLOAD,
                                          "ms_per_step": round(1e3 * sec, 4), "images_per_s": round(256 / sec, 1),
                                          "hbm_floor_us": round(b2 / (HBM_PEAK_GBS * 1e3), 1),
                                          "frac_of_hbm_floor": round(b2 / (HBM_PEAK_GBS * 1e3) / (sec * 1e6), 4)}}
+                if not args.no_roofline:
+                    out["configs"]["c2"]["roofline"] = kernel_roofline(eng, lambda: eng.train_step(x2, y2, 1.0, LR, head=False), 256, tag="c2")
             except Exception as e:
                 out["configs"] = {"error": str(e)[:200]}
             # configs[4]'s per-GPU shape and arithmetic (its 8-GPU form is the driver's): 256x256 inputs, 256-d latent, fp8 operands for
             # the GEMMs of the six 3x3 layers; the same shape in bf16 beside it.  Not the headline; parity in tests/test_gpu_fp8.py.
             try:
-                out.setdefault("configs", {})["c5"] = config5_leg()
+                out.setdefault("configs", {})["c5"] = config5_leg(roofline=not args.no_roofline)
             except Exception as e:
                 out.setdefault("configs", {})["c5"] = {"error": str(e)[:200]}
             try:

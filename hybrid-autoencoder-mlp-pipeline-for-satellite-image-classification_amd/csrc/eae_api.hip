@@ -783,7 +783,10 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
     a.c.wpack = (const bf16_t*)(c->pack + c->pk_c1); a.c.bias = c->P + c->poff[1]; a.c.out = c->y[0];
     a.c.stat_part = train ? c->stat : nullptr; a.c.B = B;
     fold_producer(c, a.c, 0, train);
-    RC(eae_launch_edge_conv(st, SRC3_NCHW_F32, EPI_FWD, a));
+    {
+      ProfBracket pb(c, EAE_PROF_SITE(0, 0), st);
+      RC(eae_launch_edge_conv(st, SRC3_NCHW_F32, EPI_FWD, a));
+    }
     RC(sync_fwd(c, st, 0, train));
     RC(bn_fwd_finalize(c, st, 0, eae_edge_tiles(B, H, W), (long long)B * (H / 2) * (W / 2), train));
   }
@@ -797,7 +800,7 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
     fold_consumer(c, a.fold, i - 1, (long long)B * a.Hin * a.Win, train);
     fp8_conv_args(c, a, i - 1, true, true);
     {
-      ProfBracket pb(c, i == 1 ? EAE_PROF_CONV2_FWD : -1, st);
+      ProfBracket pb(c, EAE_PROF_SITE(i, 0), st);
       RC(eae_launch_conv_s2(a, ENC_C[i], ENC_C[i + 1], SRC_BNRELU, EPI_FWD, st));
     }
     RC(sync_fwd(c, st, i, train));
@@ -843,7 +846,7 @@ int run_decoder(eae_ctx* c, hipStream_t st, const float* z, int B, bool train, c
     if (i > 0) fold_consumer(c, a.fold, 3 + i, (long long)B * a.Hin * a.Win, train);
     fp8_conv_args(c, a, 3 + i, true, false);
     {
-      ProfBracket pb(c, i == 2 ? EAE_PROF_DECONV3_FWD : -1, st);
+      ProfBracket pb(c, EAE_PROF_SITE(4 + i, 0), st);
       RC(eae_launch_deconv_s2(a, cin[i], cin[i] / 2, i == 0 ? SRC_RAW : SRC_BNRELU, EPI_FWD, st));
     }
     RC(sync_fwd(c, st, 4 + i, train));
@@ -978,7 +981,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     }
     sq_push(c, [=](hipStream_t ss, float* scr) {
       return eae_launch_edge_wgrad(ss, SRC3_NHWC4_BF16, c->g4, B, H, W, src_bnrelu(c->u[2], c->coef_f[6]), SRC_BNRELU, scr,
-                                   c->wscratch_floats, c->G + c->poff[32]);
+                                   c->wscratch_floats, c->G + c->poff[32], prof_hook_for(c, EAE_PROF_SITE(7, 2)));
     }, 0);
     sq_fork(c);
     // ---- deconv4: backward-data into u[2]'s BN+ReLU
@@ -1010,7 +1013,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
         fold_bwd_consumer(c, w.bfold, 4 + i, (long long)B * (Hs * 2) * (Ws * 2), false);
         if (c->fp8) w.qs = c->q->qs_wg[3 + i];
         return eae_launch_wgrad_s2(s2, w, cs, cb, i == 0 ? SRC_RAW : SRC_BNRELU, SRC_BNBWD, scr, c->wscratch_floats, c->G + c->poff[20 + 4 * i],
-                                   prof_hook_for(c, i == 2 ? EAE_PROF_DECONV3_WGRAD : -1));
+                                   prof_hook_for(c, EAE_PROF_SITE(4 + i, 2)));
       });
       if (i == 0) sq_fork(c); else fork_if_every();
       ConvArgs a = ConvArgs();
@@ -1024,14 +1027,17 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
         a.out = c->gu[i - 1]; a.stat_part = c->stat; a.yprev = c->u[i - 1]; a.prev_coef = c->coef_f[3 + i];
         fold_bwd_producer(c, a, 3 + i);
         {
-          ProfBracket pb(c, i == 2 ? EAE_PROF_DECONV3_BWD : -1, st);
+          ProfBracket pb(c, EAE_PROF_SITE(4 + i, 1), st);
           RC(eae_launch_conv_s2(a, cb, cs, SRC_BNBWD, EPI_MASK, st));
         }
         if (c->sq_forked) RC(sq_commit(c, st));
         RC(bn_bwd_fin(c, st, 3 + i, eae_conv_s2_ntiles(0, B, a.Hin, a.Win, cb), (long long)B * Hs * Ws));
       } else {
         a.out = c->gd0;
-        RC(eae_launch_conv_s2(a, cb, cs, SRC_BNBWD, EPI_PLAIN, st));
+        {
+          ProfBracket pb(c, EAE_PROF_SITE(4, 1), st);
+          RC(eae_launch_conv_s2(a, cb, cs, SRC_BNBWD, EPI_PLAIN, st));
+        }
         if (c->sq_forked) RC(sq_commit(c, st));
       }
     }
@@ -1107,7 +1113,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
       fold_bwd_consumer(c, w.bfold, i, (long long)B * Hs * Ws, false);
       if (c->fp8) w.qs = c->q->qs_wg[i - 1];
       return eae_launch_wgrad_s2(s2, w, cs, cb, SRC_BNBWD, SRC_BNRELU, scr, c->wscratch_floats, c->G + c->poff[4 * i],
-                                 prof_hook_for(c, i == 1 ? EAE_PROF_CONV2_WGRAD : -1));
+                                 prof_hook_for(c, EAE_PROF_SITE(i, 2)));
     });
     if (i != 3) sq_fork(c); else fork_if_every();
     ConvArgs a = ConvArgs();
@@ -1120,7 +1126,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     fp8_conv_args(c, a, i - 1, false, false);
     take_sig(c, a);
     {
-      ProfBracket pb(c, i == 1 ? EAE_PROF_CONV2_BWD : -1, st);
+      ProfBracket pb(c, EAE_PROF_SITE(i, 1), st);
       RC(eae_launch_deconv_s2(a, cs, cb, SRC_BNBWD, EPI_MASK, st));
     }
     if (c->sq_forked) RC(sq_commit(c, st));

@@ -62,6 +62,9 @@ __device__ __forceinline__ uint32_t relu2(uint32_t p) { // ReLU on two packed bf
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v, z));
 }
 
+// fp32 ReLU that lets a NaN through like torch.relu does (fmaxf returns the other operand): a diverged run stays loud downstream
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
+
 // Per-thread coefficients of 8 consecutive channels for a source transform (as 4 fp32 pairs).
 template <int MODE> struct ChanCoef {
   f32x2 a[4], b[4], c[4];
@@ -92,10 +95,11 @@ struct SrcRsrc {
 template <int MODE> struct RawPiece { u32x4 v0, v1; };
 
 // byte_off = byte offset of the piece inside the tensor, or OOB_OFF for a piece outside the image
-template <int MODE>
+// AUX = cache-policy bits of the load (0 = default, 2 = nt: streamed once, do not keep in L2)
+template <int MODE, int AUX = 0>
 __device__ __forceinline__ void load_piece_b(const SrcRsrc& rs, uint32_t byte_off, RawPiece<MODE>& r) {
-  r.v0 = __builtin_amdgcn_raw_buffer_load_b128(rs.r0, byte_off, 0, 0);
-  if (MODE == SRC_BNBWD) r.v1 = __builtin_amdgcn_raw_buffer_load_b128(rs.r1, byte_off, 0, 0);
+  r.v0 = __builtin_amdgcn_raw_buffer_load_b128(rs.r0, byte_off, 0, AUX);
+  if (MODE == SRC_BNBWD) r.v1 = __builtin_amdgcn_raw_buffer_load_b128(rs.r1, byte_off, 0, AUX);
 }
 
 // compatibility form (element offset + validity flag)

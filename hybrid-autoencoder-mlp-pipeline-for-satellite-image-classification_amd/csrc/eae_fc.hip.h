@@ -40,7 +40,7 @@ __device__ __forceinline__ uint4 fc_load_a(const SrcDesc& s, size_t off, bool va
     float x[8];
     unpack8(r, x);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = fmaxf(fmaf(coef[ch0 + j], x[j], coef[256 + ch0 + j]), 0.f);
+    for (int j = 0; j < 8; ++j) x[j] = relu_nan(fmaf(coef[ch0 + j], x[j], coef[256 + ch0 + j]));
     r = pack8(x);
   }
   return r;
@@ -211,7 +211,7 @@ __device__ __forceinline__ uint4 fc_finish_raw(const FcRaw<MODE>& r, bool valid,
     float x[8];
     unpack8(r.v, x);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = fmaxf(fmaf(cs[j], x[j], ct[j]), 0.f);
+    for (int j = 0; j < 8; ++j) x[j] = relu_nan(fmaf(cs[j], x[j], ct[j]));
     o = pack8(x);
   } else {
     o = r.v;

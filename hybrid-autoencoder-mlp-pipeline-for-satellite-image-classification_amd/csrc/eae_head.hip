@@ -82,7 +82,7 @@ __global__ EAE_NO_PK __launch_bounds__(256, 5) void head_kernel(HeadArgs a) {   
 #pragma unroll 4
     for (int j = 0; j < 128; j += 4) {
       const float4 h = *reinterpret_cast<const float4*>(hp + r * HS + j), w = *reinterpret_cast<const float4*>(w2 + c * HS + j);
-      s = fmaf(fmaxf(h.x, 0.f), w.x, s); s = fmaf(fmaxf(h.y, 0.f), w.y, s); s = fmaf(fmaxf(h.z, 0.f), w.z, s); s = fmaf(fmaxf(h.w, 0.f), w.w, s);
+      s = fmaf(relu_nan(h.x), w.x, s); s = fmaf(relu_nan(h.y), w.y, s); s = fmaf(relu_nan(h.z), w.z, s); s = fmaf(relu_nan(h.w), w.w, s);
     }
     lg[r * HC + c] = s;
   }
@@ -176,7 +176,7 @@ __global__ EAE_NO_PK __launch_bounds__(256, 5) void head_kernel(HeadArgs a) {   
     int c = i >> 7, j = i & 127;
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < HR_; ++r) s = fmaf(lg[r * HC + c], fmaxf(hp[r * HS + j], 0.f), s);
+    for (int r = 0; r < HR_; ++r) s = fmaf(lg[r * HC + c], relu_nan(hp[r * HS + j]), s);
     gp[128 * L + 128 + i] = s;
   }
   if (tid < ((C + 3) & ~3)) {

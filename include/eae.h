@@ -173,16 +173,19 @@ int eae_decoder_backward(eae_ctx* ctx, void* stream, long long generation, const
  * the summed time of an EMPTY bracket recorded right behind each timed one (what the two event records cost by themselves) and
  * the number of launches measured.  site 0 switches the timing off.  Kernel behind each site (rocprofv3 name): */
 #define EAE_PROF_OFF 0
-#define EAE_PROF_CONV2_FWD 1      /* igemm_s2_kernel<0, 32, 64, 64, 16, 8, 1, 1, 0>   enc.conv2 forward */
-#define EAE_PROF_CONV2_BWD 2      /* igemm_s2_kernel<1, 64, 32, 32, 16, 8, 1, 2, 1>   enc.conv2 backward-data */
-#define EAE_PROF_DECONV3_BWD 3    /* igemm_s2_kernel<0, 32, 64, 64, 16, 8, 1, 2, 1>   dec.deconv3 backward-data */
-#define EAE_PROF_CONV2_WGRAD 4    /* wgrad_s2_kernel<64, 32, 16, 8, 1, 2, 1>          enc.conv2 weight gradient */
-#define EAE_PROF_DECONV3_WGRAD 5  /* wgrad_s2_kernel<64, 32, 16, 8, 1, 1, 2>          dec.deconv3 weight gradient */
-#define EAE_PROF_DECONV4_LOSS 6   /* deconv4_loss_kernel<1>                           dec.deconv4 + sigmoid + MSE + gradient */
-#define EAE_PROF_CONV1_WGRAD 7    /* edge_wgrad_kernel<0, 2>                          enc.conv1 weight gradient */
-#define EAE_PROF_DECONV4_BWD 8    /* edge_conv_kernel<1, 1>                           dec.deconv4 backward-data */
-#define EAE_PROF_DECONV3_FWD 9    /* igemm_s2_kernel<1, 64, 32, 32, 16, 8, 1, 1, 0>   dec.deconv3 forward */
-#define EAE_PROF_NSITES 10
+/* site = EAE_PROF_SITE(layer, role): layer 0-3 = enc.conv1-4, 4-7 = dec.deconv1-4; role 0 forward, 1 backward-data, 2 weight gradient
+ * (layer 0 has no backward-data; layer 7's forward is the fused deconv4 + sigmoid + MSE kernel) */
+#define EAE_PROF_SITE(layer, role) (16 + 3 * (layer) + (role))
+#define EAE_PROF_CONV2_FWD EAE_PROF_SITE(1, 0)      /* igemm_s2_kernel<0, 32, 64, 64, 16, 8, 1, 1, 0>   enc.conv2 forward */
+#define EAE_PROF_CONV2_BWD EAE_PROF_SITE(1, 1)      /* igemm_s2_kernel<1, 64, 32, 32, 16, 8, 1, 2, 1>   enc.conv2 backward-data */
+#define EAE_PROF_DECONV3_BWD EAE_PROF_SITE(6, 1)    /* igemm_s2_kernel<0, 32, 64, 64, 16, 8, 1, 2, 1>   dec.deconv3 backward-data */
+#define EAE_PROF_CONV2_WGRAD EAE_PROF_SITE(1, 2)    /* wgrad_s2_kernel<64, 32, 16, 8, 1, 2, 1>          enc.conv2 weight gradient */
+#define EAE_PROF_DECONV3_WGRAD EAE_PROF_SITE(6, 2)  /* wgrad_s2_kernel<64, 32, 16, 8, 1, 1, 2>          dec.deconv3 weight gradient */
+#define EAE_PROF_DECONV4_LOSS EAE_PROF_SITE(7, 0)   /* deconv4_loss_kernel<1>                           dec.deconv4 + sigmoid + MSE + gradient */
+#define EAE_PROF_CONV1_WGRAD EAE_PROF_SITE(0, 2)    /* edge_wgrad_kernel<0, 2>                          enc.conv1 weight gradient */
+#define EAE_PROF_DECONV4_BWD EAE_PROF_SITE(7, 1)    /* edge_conv_kernel<1, 1>                           dec.deconv4 backward-data */
+#define EAE_PROF_DECONV3_FWD EAE_PROF_SITE(6, 0)    /* igemm_s2_kernel<1, 64, 32, 32, 16, 8, 1, 1, 0>   dec.deconv3 forward */
+#define EAE_PROF_NSITES 40
 int eae_profile_enable(eae_ctx* ctx, int site);
 /* diagnostic: copy an internal fp32 buffer (0 z, 1 dz, 2 dz_head, 3 head partials, 4 CE partials) to dst (device) */
 int eae_debug_copy(eae_ctx* ctx, int which, float* dst, long long n);
