@@ -13,27 +13,64 @@ sys.path.insert(0, ROOT)
 
 def test_dominant_kernel_selection_matches_the_committed_summary():
     """The kernel bench.py times live is the largest single-launch-site row of the newest committed rocprofv3 summary, named exactly
-    as rocprofv3 names it, and priced with the same bytes / FLOPs tools/kernel_report.py uses for that row."""
+    as rocprofv3 names it; gate rows (one waiting wave) are never picked; the profile carries the commit it was taken at."""
     from eae_amd import profile_hooks as ph
-    stats = ph.newest_stats(512)
-    assert stats and os.path.basename(stats).startswith("r02_"), stats
+    stats = ph.newest_stats("b512")
+    assert stats and os.path.basename(stats).startswith(("r02_", "r03_")), stats
     name, row, skipped = ph.pick_dominant(stats)
     rows = {r["Name"]: r for r in csv.DictReader(open(stats))}
-    assert name in rows and name in ph.KERNELS
+    assert name in rows and ph.site_of(name) is not None and "gate_kernel" not in name
     # nothing with a launch site of its own is larger
     for r in rows.values():
-        if r["Name"] in ph.KERNELS:
+        if ph.site_of(r["Name"]) is not None:
             assert float(r["TotalDurationNs"]) <= float(row["TotalDurationNs"])
     # rows skipped on the way down are helpers launched several times per step
     assert all(s["calls"] > int(row["Calls"]) for s in skipped), skipped
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import kernel_report as kr
-    site, role, bpi, mf = ph.KERNELS[name]
-    frag = name.split("(")[0].replace("void ", "")
-    match = [t for t in kr.T if t[0] in name]
-    assert match and match[0][2] == bpi and abs(match[0][3] - mf) < 1e-9, (frag, match)
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_b512.json")))["kernels"]
+    rnd = os.path.basename(stats)[:3]
+    pmc = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_b512.json")))["kernels"]
     assert name in pmc and pmc[name]["traffic_bytes"] > 0 and 0.0 < pmc[name]["mfma_util"] < 1.0
+    if rnd != "r02":
+        assert ph._commit_of(stats) == json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_profile_meta.json")))["commit"]
+
+
+def test_site_of_and_site_model_on_every_kernel_name_of_the_committed_summaries():
+    """Every conv-layer kernel name in the committed summaries maps to the launch site of its layer and role (from its template
+    arguments, whatever tile geometry), and the byte / FLOP model reproduces SURVEY.md 8d's hand-derived figures at 64x64."""
+    from eae_amd import profile_hooks as ph
+    S = ph.prof_site
+    known = {"void igemm_s2_kernel<0, 32, 64, 64, 16, 8, 1, 1, 0>(ConvArgs)": S(1, 0),
+             "void igemm_s2_kernel<1, 64, 32, 32, 16, 8, 1, 2, 1>(ConvArgs)": S(1, 1),
+             "void igemm_s2_kernel<0, 32, 64, 64, 16, 8, 1, 2, 1>(ConvArgs)": S(6, 1),
+             "void igemm_s2_kernel<0, 128, 256, 64, 4, 4, 8, 2, 2>(ConvArgs)": S(4, 1),
+             "void igemm2_s2_kernel<0, 128, 256, 64, 4, 4, 8, 1, 0, 1>(ConvArgs)": S(3, 0),
+             "void igemm2_s2_kernel<1, 256, 128, 64, 4, 4, 4, 0, 0, 1>(ConvArgs)": S(4, 0),
+             "void wgrad_s2_kernel<64, 32, 16, 8, 1, 2, 1>(WgradArgs)": S(1, 2),
+             "void wgrad_s2_kernel<64, 32, 16, 8, 1, 1, 2>(WgradArgs)": S(6, 2),
+             "void wgrad_s2_kernel<256, 128, 4, 4, 8, 0, 2>(WgradArgs)": S(4, 2),
+             "void wgrad_s2_kernel<256, 128, 4, 4, 8, 2, 1>(WgradArgs)": S(3, 2),
+             "void deconv4_loss_kernel<1>(Deconv4Args)": S(7, 0), "void edge_wgrad_kernel<0, 2>(EdgeWgradArgs)": S(0, 2),
+             "void edge_wgrad_kernel<1, 1>(EdgeWgradArgs)": S(7, 2), "void edge_conv_kernel<1, 1>(EdgeArgs)": S(7, 1),
+             "void edge_conv_kernel<0, 0>(EdgeArgs)": S(0, 0), "void igemm8_s2_kernel<1, 64, 32, 32, 16, 8, 1, 2, 1>(ConvArgs)": S(1, 1)}
+    for n, s in known.items():
+        assert ph.site_of(n) == s, n
+    for n in ("adam_kernel(AdamArgs)", "void head_kernel<16>(HeadArgs)", "gate_kernel(GateArgs)", "void fc_nt_kernel<1, 0>(FcNtArgs)"):
+        assert ph.site_of(n) is None
+    X, Y1, Y2 = 3 * 64 * 64, 32 * 32 * 32, 16 * 16 * 64
+    MF, EDGE = 2.0 * 256 * 288 * 64 / 1e6, 2.0 * 1024 * 27 * 32 / 1e6
+    want = {S(1, 0): (2 * Y1 + 2 * Y2, MF), S(1, 1): (4 * Y2 + 4 * Y1, MF), S(6, 1): (4 * Y1 + 4 * Y2, MF), S(1, 2): (4 * Y2 + 2 * Y1, MF),
+            S(6, 2): (2 * Y2 + 4 * Y1, MF), S(7, 0): (2 * Y1 + 4 * X + 8 * 64 * 64, EDGE), S(0, 2): (4 * X + 4 * Y1, EDGE),
+            S(7, 1): (8 * 64 * 64 + 4 * Y1, EDGE), S(6, 0): (2 * Y2 + 2 * Y1, MF), S(3, 0): (2 * 8 * 8 * 128 + 2 * 4 * 4 * 256, MF)}
+    for s, (b, mf) in want.items():
+        role, bpi, m = ph.site_model(s, 64, 64)
+        assert bpi == b and abs(m - mf) < 1e-9, (s, role, bpi, b)
+    # 256x256 inputs: every map 16x larger
+    for s in ph.all_sites():
+        assert ph.site_model(s, 256, 256)[1] == 16 * ph.site_model(s, 64, 64)[1]
+    assert len(ph.all_sites()) == 23
+    for f in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r03_bench_*_kernel_stats.csv"))):
+        for r in csv.DictReader(open(f)):
+            if any(k in r["Name"] for k in ("igemm", "wgrad_s2", "wgrad8", "edge_", "deconv4_loss")):
+                assert ph.site_of(r["Name"]) is not None, (f, r["Name"])
 
 
 @pytest.mark.gpu
@@ -56,6 +93,7 @@ def test_bench_line_contract_and_roofline_arithmetic():
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9) <= 0.01 * rf["achieved"]
     assert abs(rf["avg_launch_us"] - (rf["event_bracket_us"] - rf["empty_bracket_us"])) < 0.05
     prof = rf["from_committed_profile"]
-    assert prof["summary"].startswith("profiles/r02_") and rf["traffic"] == prof["pmc_traffic_bytes_per_launch"]
+    assert prof["summary"].startswith(("profiles/r02_", "profiles/r03_")) and rf["traffic"] == prof["pmc_traffic_bytes_per_launch"]
+    assert prof["summary_commit"]
     # the live duration and the committed rocprofv3 average of the same kernel agree (tracing changes how the streams line up)
     assert 0.6 <= rf["avg_launch_us"] / prof["rocprof_avg_us"] <= 1.4, (rf["avg_launch_us"], prof["rocprof_avg_us"])
