@@ -285,7 +285,7 @@ __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc*
     }
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&q->amax_w[d.q_layer], __float_as_uint(mx));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&q->amax_w[d.q_layer][(blockIdx.x * 4 + (threadIdx.x >> 6)) & (FP8_AMAX_SLOTS - 1)], __float_as_uint(mx));
     return;
   }
   if ((d.mode == PACK_3x3_P1 || d.mode == PACK_3x3_P2) && !d.out_f32) {
@@ -382,12 +382,25 @@ __device__ __forceinline__ float fp8_scale_from(unsigned amax_bits, float maxv, 
   return exp2f(fminf(fmaxf(e, -60.f), 60.f));
 }
 __global__ EAE_NO_PK void fp8_scales_kernel(Fp8State* q) {
-  const int i = threadIdx.x;
-  if (i < 6) {
-    q->s_act[i] = fp8_scale_from(q->amax_act[i], 448.f, q->s_act[i]);
-    q->s_grad[i] = fp8_scale_from(q->amax_grad[i], 57344.f, q->s_grad[i]);
-    q->s_w[i] = fp8_scale_from(q->amax_w[i], 448.f, q->s_w[i]);
-    q->amax_act[i] = 0; q->amax_grad[i] = 0; q->amax_w[i] = 0;
+  static_assert(FP8_AMAX_SLOTS == 64, "one word per lane");
+  const int lane = threadIdx.x;
+  unsigned ma[6], mg[6], mw[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    ma[i] = q->amax_act[i][lane]; mg[i] = q->amax_grad[i][lane]; mw[i] = q->amax_w[i][lane];
+    q->amax_act[i][lane] = 0; q->amax_grad[i][lane] = 0; q->amax_w[i][lane] = 0;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {       // (non-negative float bits order like unsigned integers)
+      const unsigned a = __shfl_xor(ma[i], sh), g = __shfl_xor(mg[i], sh), w = __shfl_xor(mw[i], sh);
+      ma[i] = a > ma[i] ? a : ma[i]; mg[i] = g > mg[i] ? g : mg[i]; mw[i] = w > mw[i] ? w : mw[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    if (lane != i) continue;
+    q->s_act[i] = fp8_scale_from(ma[i], 448.f, q->s_act[i]);
+    q->s_grad[i] = fp8_scale_from(mg[i], 57344.f, q->s_grad[i]);
+    q->s_w[i] = fp8_scale_from(mw[i], 448.f, q->s_w[i]);
     const float sa = q->s_act[i], sg = q->s_grad[i], sw = q->s_w[i];
     q->qs_fwd[i][0] = 1.f / sa; q->qs_fwd[i][1] = 1.f / (sa * sw);
     q->qs_bwd[i][0] = 1.f / sg; q->qs_bwd[i][1] = 1.f / (sg * sw);

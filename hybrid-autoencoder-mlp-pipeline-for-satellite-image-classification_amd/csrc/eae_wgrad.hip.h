@@ -93,7 +93,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     }
     else { oblk = bid % NBLK; slice = bid / NBLK; }
   }
-  const int cs0 = (oblk / (CB / 32)) * 64, cb0 = (oblk % (CB / 32)) * 32;
+  // a slice whose blocks are split over two XCDs: adjacent block ids share the channel block of the operand with MORE bytes per tile
+  // (the SRC_BNBWD one: g and y), so that each XCD fetches half of it and all of the lighter one (dec.deconv1: 2.05x -> ~1.4x)
+  const int cs0 = (BG ? oblk % (CS / 64) : oblk / (CB / 32)) * 64, cb0 = (BG ? oblk / (CS / 64) : oblk % (CB / 32)) * 32;
   const int t_first = slice * a.tiles_per_block;
   int t_end = t_first + a.tiles_per_block;
   if (t_end > a.ntiles) t_end = a.ntiles;

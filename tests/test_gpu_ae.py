@@ -697,6 +697,32 @@ def test_ce_mse_ratio_probe_vs_oracle():
         assert 5.0 < r < 100.0           # the reference's histogram sits around 25-38 for real images (R.md:532)
 
 
+def test_ce_mse_ratio_probe_concurrent_trials_vs_oracle():
+    """SURVEY 8f N4 with concurrent=K: K model + engine pairs on K streams, the parameter draws still one sequence in trial order (a
+    turnstile hands torch's generator from trial to trial).  Every trial's captured parameters replayed through the bf16 oracle; the
+    trials are captured in order; a second run with the same seed gives the same ratios (the forwards overlap, the draws do not)."""
+    import eae_amd
+    x, y = gu.make_images(16, 321)
+    runs = []
+    for _ in range(2):
+        states, order = [], []
+
+        def grab(i, model):
+            order.append(i)
+            states.append({k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
+
+        torch.manual_seed(78)
+        ratios = eae_amd.ce_mse_ratio_probe([(torch.from_numpy(x), torch.from_numpy(y))], n_models=7, on_model=grab, concurrent=3)
+        assert order == list(range(7)) and len(ratios) == 7
+        runs.append((ratios, states))
+    assert runs[0][0] == runs[1][0]
+    for r, sd in zip(*runs[0]):
+        out = O.ae_forward(sd, x, train=True, quant="bf16")
+        _, l_r, l_c = O.ae_loss(out, x, y, 1.0)
+        assert abs(r - float(l_c) / float(l_r)) <= 1e-2 * float(l_c) / float(l_r), (r, l_c, l_r)
+    assert len({s["enc.encoder.0.weight"].tobytes() for s in runs[0][1]}) == 7          # seven different draws
+
+
 PRE_BN_BIAS = {f"enc.encoder.{i}.bias" for i in (0, 3, 6, 9)} | {f"dec.decoder.{i}.bias" for i in (1, 4, 7)}
 
 

@@ -80,7 +80,8 @@ def main():
             out["kernels"][k] = e
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{tag}.json")
         json.dump(out, open(path, "w"), indent=1)
-        steps = int(run.split("pmc_steps=")[1]) + 2 if "pmc_steps=" in run else 7
+        # steps seen by the counter pass = launches of a once-per-step kernel (fp8 calibration adds gradient steps of its own)
+        steps = max([v["launches"] for k, v in out["kernels"].items() if "deconv4_loss_kernel" in k] or [7])
         ours = [v for k, v in out["kernels"].items() if not k.startswith(("void at::", "__amd_rocclr"))]
         per_step = sum(v["traffic_bytes"] * v["launches"] for v in ours) / steps
         out["hbm_traffic_bytes_per_step"] = int(per_step)
