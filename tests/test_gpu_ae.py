@@ -891,8 +891,9 @@ def _stall(seconds):
     torch.cuda.synchronize()
     e0.record(); torch.cuda._sleep(probe); e1.record()
     torch.cuda.synchronize()
-    per_tick = e0.elapsed_time(e1) * 1e-3 / probe
-    torch.cuda._sleep(int(seconds / per_tick))
+    per_probe = max(e0.elapsed_time(e1) * 1e-3, 1e-4)      # seconds one probe-sized sleep takes on this box
+    for _ in range(int(seconds / per_probe) + 1):           # (many short sleeps: one long tick count overflows the kernel's 32-bit counter)
+        torch.cuda._sleep(probe)
 
 
 def test_caller_stream_stalled_for_seconds_in_front_of_a_step_is_waited_for():
