@@ -120,6 +120,7 @@ struct eae_ctx {
   unsigned long long* accb[7] = {};      // BatchNorm-backward accumulators (same region and layout, behind the forward ones)
   bool fold_bwd = true;
   uint8_t* acc_base = nullptr;
+  size_t poison_off = 0;       // byte offset of the step-wide non-finite word inside the accumulator region (cleared with it)
   size_t acc_bytes = 0;
   bool acc_clean = false;          // all zero (cleared by the engine's own Adam launch or at creation)
   // synchronized BatchNorm across data-parallel replicas (eae_set_sync_bn): the batch statistics of every BN layer are summed
@@ -253,7 +254,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
       acc_total += (size_t)cp * 2 * BN_C[l] * 8 + (size_t)BN_C[l] * 8;        // + the layer's [C] sticky non-finite flag words (BnAcc::flag)
     }
   }
-  size_t o_accb = carve(2 * acc_total);  // forward accumulators, then the backward ones (cleared together)   // conv1 weight gradient (last kernel of the backward, runs on the main stream)
+  size_t o_accb = carve(2 * acc_total + 32);  // forward accumulators, then the backward ones (cleared together)   // conv1 weight gradient (last kernel of the backward, runs on the main stream)
   const int ksplit = (int)(c->K / 128);
   size_t o_fcp = carve((size_t)ksplit * Bm * c->Lp * 4);
   size_t o_mse = carve(std::max((size_t)eae_edge_tiles((int)Bm, c->H, c->W), (size_t)((Bm * c->H * c->W + 255) / 256)) * 4 * 4);
@@ -313,7 +314,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   }
   for (int l = 0; l < 7; ++l) { c->coef_f[l] = (float*)(b + o_cf[l]); c->coef_b[l] = (float*)(b + o_cb[l]); }
   c->stat = (float*)(b + o_stat); c->wscratch = (float*)(b + o_wscr); c->wscratch_main = (float*)(b + o_wscrm);
-  c->acc_base = b + o_accb; c->acc_bytes = (2 * acc_total + 15) & ~(size_t)15;
+  c->acc_base = b + o_accb; c->poison_off = (2 * acc_total + 15) & ~(size_t)15; c->acc_bytes = c->poison_off + 16;      // + the step-wide poison word
   for (int l = 0; l < 7; ++l) c->accf[l] = (unsigned long long*)(b + o_accb + o_acc[l]);
   for (int l = 0; l < 7; ++l) c->accb[l] = (unsigned long long*)(b + o_accb + acc_total + o_acc[l]);
   for (int i = 0; i < c->nx; ++i) c->wscratchx[i] = (float*)(b + o_wscrx[i]); c->fcpart = (float*)(b + o_fcp);
@@ -646,9 +647,11 @@ int join_side(eae_ctx* c, hipStream_t st) {
   return 0;
 }
 
+unsigned* poison_word(const eae_ctx* c) { return reinterpret_cast<unsigned*>(c->acc_base + c->poison_off); }
 int ensure_packed(eae_ctx* c, hipStream_t st) {
   if (c->packed) return 0;
-  RC(eae_launch_pack_all(st, c->descs_dev, c->ndesc, c->P, c->pack, c->fp8 ? c->q : nullptr));
+  // (the pack kernel also clears the step-wide non-finite word: the optimizer kernel that clears the accumulators READS that word)
+  RC(eae_launch_pack_all(st, c->descs_dev, c->ndesc, c->P, c->pack, c->fp8 ? c->q : nullptr, poison_word(c)));
   c->packed = true;
   return 0;
 }
@@ -693,6 +696,7 @@ void fold_consumer(eae_ctx* c, BnFold& f, int l, long long count, bool train) {
   if (!train || !c->fold_fwd) return;
   count *= c->sync_world;
   f.acc = c->accf[l]; f.copies = c->acc_copies[l]; f.inv_scale = 1.0f / ACC_SCALE_FWD; f.count = (float)count; f.flag = acc_flag(c, c->accf[l], l);
+  f.poison = poison_word(c);
   f.momentum = BN_MOM; f.eps = BN_EPS;
   f.gamma = c->P + c->poff[BN_GAMMA_IDX[l]]; f.beta = c->P + c->poff[BN_GAMMA_IDX[l] + 1];
   f.rm = c->bnrun + c->bnoff[2 * l]; f.rv = c->bnrun + c->bnoff[2 * l + 1]; f.nbt = c->nbt ? c->nbt + l : nullptr;
@@ -733,6 +737,7 @@ void fold_bwd_consumer(eae_ctx* c, BnBwdFold& f, int l, long long count, bool wr
   f = BnBwdFold();
   if (!bwd_folded(c, l)) return;
   f.acc = c->accb[l]; f.copies = bwd_copies(c, l); f.inv_scale = 1.0f / ACC_SCALE_BWD; f.flag = acc_flag(c, c->accb[l], l);
+  f.poison = poison_word(c);
   f.count = c->bwd_eval ? __builtin_inff() : (float)count;
   f.gamma = c->P + c->poff[BN_GAMMA_IDX[l]]; f.coef_fwd = c->coef_f[l];
   if (writer) {
@@ -929,12 +934,12 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
       float *accum = io->loss_accum, *last = io->loss_last;
       const int ntile = eae_edge_tiles(B, c->H, c->W);
       sq_push(c, [=](hipStream_t ls, float*) {
-        return eae_launch_loss_finalize(ls, c->msepart, ntile, c->cepart, n_ce, alpha, numel, B, c->G + c->poff[33], accum, last);
+        return eae_launch_loss_finalize(ls, c->msepart, ntile, c->cepart, n_ce, alpha, numel, B, c->G + c->poff[33], accum, last, poison_word(c));
       }, 0);
       sq_fork(c);                  // released by the first kernel of the backward-data chain (backward_impl commits behind it)
     } else {
       RC(eae_launch_loss_finalize(st, c->msepart, eae_edge_tiles(B, c->H, c->W), c->cepart, n_ce, io->alpha, numel, B,
-                                  want_grad ? c->G + c->poff[33] : nullptr, io->loss_accum, io->loss_last));
+                                  want_grad ? c->G + c->poff[33] : nullptr, io->loss_accum, io->loss_last, poison_word(c)));
     }
   }
   return 0;
@@ -1238,7 +1243,7 @@ extern "C" int eae_adam_step(eae_ctx* c, void* stream, float lr, float weight_de
   if (!c || !c->P || !c->G || !c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: parameter, gradient and moment arenas must be bound");
   c->adam_step += 1;
   RC(eae_launch_adam_scaled((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step, 1.0f,
-                            c->acc_base, (long long)c->acc_bytes, c->sigwords + 8, c->last_loss));
+                            c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss));
   c->packed = false; c->acc_clean = true;
   return 0;
 }
@@ -1275,7 +1280,7 @@ extern "C" int eae_adam_step_scaled(eae_ctx* c, void* stream, float lr, float we
   if (!c || !c->P || !c->G || !c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: parameter, gradient and moment arenas must be bound");
   c->adam_step += 1;
   RC(eae_launch_adam_scaled((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step, grad_scale,
-                            c->acc_base, (long long)c->acc_bytes, c->sigwords + 8, c->last_loss));
+                            c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss));
   c->packed = false; c->acc_clean = true;
   return 0;
 }
@@ -1309,7 +1314,7 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
     int rc = forward_impl(c, st, io, true);
     if (!rc) rc = backward_impl(c, st, io);
     if (!rc) rc = eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f,
-                                         c->acc_base, (long long)c->acc_bytes, c->sigwords + 8, c->last_loss);
+                                         c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss);
     c->packed = false; c->acc_clean = (rc == 0);
     return rc;
   }
@@ -1324,7 +1329,7 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
   c->capturing = capture;
   int rc = forward_impl(c, st, io, true);
   if (!rc) rc = backward_impl(c, st, io);
-  if (!rc) rc = eae_launch_adam_dyn(st, c->P, c->G, c->M, c->V, c->poff[38], 0.9, 0.999, 1e-8, c->dyn, c->sigwords + 8, c->last_loss);
+  if (!rc) rc = eae_launch_adam_dyn(st, c->P, c->G, c->M, c->V, c->poff[38], 0.9, 0.999, 1e-8, c->dyn, c->sigwords + 8, poison_word(c), c->last_loss);
   c->capturing = false;
   c->packed = false;
   if (capture) {
@@ -1539,7 +1544,7 @@ extern "C" int eae_ae_dp_train_step(eae_ctx* c, void* stream, const eae_step_io*
     RC(eae_dp_allreduce_bucket(c, st, 0, total));
   }
   RC(eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f / (float)c->dp_world,
-                            c->acc_base, (long long)c->acc_bytes, c->sigwords + 8, c->last_loss));
+                            c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss));
   c->packed = false; c->acc_clean = true;
   return 0;
 }

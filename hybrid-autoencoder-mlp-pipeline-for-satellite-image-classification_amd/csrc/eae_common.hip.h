@@ -171,6 +171,7 @@ struct BnFold {
   float* rm; float* rv; long long* nbt;
   float* coef_out;           // [4][C]: s, t, mean, invstd
   const unsigned long long* flag;  // [C] the layer's non-finite flags (BnAcc::flag)
+  unsigned* poison;          // step-wide sticky word (cleared with the accumulators): the writer workgroup sets it when a channel is flagged
 };
 __device__ __forceinline__ void bn_acc_add(const BnAcc& b, int C, int tile_id, int which, int ch, float v) {
   unsigned long long* p = b.acc + ((size_t)(tile_id & (b.copies - 1)) * 2 + which) * C + ch;
@@ -231,6 +232,10 @@ __device__ __forceinline__ void bn_fold_fwd_finish(const BnFold& f, const BnFold
     const float invstd = 1.0f / sqrtf((float)var + f.eps);
     const float s = f.gamma[ch] * invstd, t = f.beta[ch] - (float)mean * s;
     table[ch] = s; table[C + ch] = t; table[2 * C + ch] = (float)mean; table[3 * C + ch] = invstd;
+    // The NaN coefficients poison this channel's activations, but not reliably what follows: the packed-bf16 ReLU of the consumers
+    // is an integer max, which turns a negative-signed NaN into 0 (measured: a NaN weight of enc.conv2 left every later layer and the
+    // loss finite).  The step-wide word makes the step loud whatever the data does: loss_finalize and the optimizer kernel read it.
+    if (writer && poisoned && f.poison != nullptr) __hip_atomic_fetch_or(f.poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (writer) {
       f.coef_out[ch] = s; f.coef_out[C + ch] = t; f.coef_out[2 * C + ch] = (float)mean; f.coef_out[3 * C + ch] = invstd;
       if (f.rm) {
@@ -269,6 +274,7 @@ struct BnBwdFold {
   float* dgamma; float* dbeta; float* coef_out;    // [C], [C], [3][C]: written by the `writer` workgroup (each may be nullptr)
   float* dbias;              // eval-mode backward only: gradient of the bias in FRONT of this BatchNorm, A[c] * sum g (train mode: zero)
   const unsigned long long* flag;  // [C] the layer's non-finite flags (BnAcc::flag of the backward accumulators)
+  unsigned* poison;          // step-wide sticky word, as in BnFold
 };
 template <int C>
 __device__ __forceinline__ void bn_fold_bwd_load(const BnBwdFold& f, BnFoldRegsB& r, int tid = threadIdx.x) {
@@ -296,6 +302,7 @@ __device__ __forceinline__ void bn_fold_bwd_finish(const BnBwdFold& f, const BnF
     const float Bc = -A * invstd * dg / f.count;
     const float Cc = -A * db / f.count - Bc * mean;
     table[ch] = A; table[C + ch] = Bc; table[2 * C + ch] = Cc;
+    if (writer && poisoned && f.poison != nullptr) __hip_atomic_fetch_or(f.poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (writer) {
       if (f.dbeta) f.dbeta[ch] = db;
       if (f.dgamma) f.dgamma[ch] = dg;

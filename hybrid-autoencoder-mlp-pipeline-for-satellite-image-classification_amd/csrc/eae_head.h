@@ -18,4 +18,4 @@ int eae_launch_head(hipStream_t st, const HeadArgs& a);
 int eae_head_blocks(int B, int L);     // partial rows of loss_part / grad_part = blocks of the launch for latent width L
 int eae_launch_ce_mean(hipStream_t st, const float* ce_part, int n, int B, float* out2);
 int eae_launch_loss_finalize(hipStream_t st, const float* mse_part, int n_mse, const float* ce_part, int n_ce, float alpha,
-                             double numel, int B, float* db4, float* accum, float* last);
+                             double numel, int B, float* db4, float* accum, float* last, const unsigned* poison = nullptr);

@@ -226,7 +226,7 @@ __device__ __forceinline__ double lf_wave_sum(double v) {
   return v;
 }
 __global__ EAE_NO_PK __launch_bounds__(256) void loss_finalize_kernel(const float* mse_part, int n_mse, const float* ce_part, int n_ce, float alpha,
-                                                             float inv_numel, float B, float* db4, float* accum, float* last) {
+                                                             float inv_numel, float B, float* db4, float* accum, float* last, const unsigned* poison) {
   __shared__ double red[4][6];
   const int tid = threadIdx.x;
   double s[6] = {0, 0, 0, 0, 0, 0};
@@ -256,6 +256,8 @@ __global__ EAE_NO_PK __launch_bounds__(256) void loss_finalize_kernel(const floa
     float mse = (float)(r[0] * inv_numel);
     float cem = n_ce ? (float)(r[4] / B) : 0.f;
     float loss = alpha * mse + cem;
+    // a BatchNorm layer of this step saw non-finite statistics (bn_fold_fwd_finish): the losses read NaN like the reference's
+    if (poison != nullptr && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) loss = mse = cem = __builtin_nanf("");
     if (db4) { db4[0] = (float)r[1]; db4[1] = (float)r[2]; db4[2] = (float)r[3]; }
     if (accum) { accum[0] += loss * B; accum[1] += mse * B; accum[2] += cem * B; accum[3] += B; accum[4] += (float)r[5]; }
     if (last) { last[0] = loss; last[1] = mse; last[2] = cem; }
@@ -263,9 +265,9 @@ __global__ EAE_NO_PK __launch_bounds__(256) void loss_finalize_kernel(const floa
 }
 
 int eae_launch_loss_finalize(hipStream_t st, const float* mse_part, int n_mse, const float* ce_part, int n_ce, float alpha,
-                             double numel, int B, float* db4, float* accum, float* last) {
+                             double numel, int B, float* db4, float* accum, float* last, const unsigned* poison) {
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, mse_part, n_mse, ce_part, n_ce, alpha,
-                     (float)(1.0 / numel), (float)B, db4, accum, last);
+                     (float)(1.0 / numel), (float)B, db4, accum, last, poison);
   EAE_LAUNCH_CHECK();
   return 0;
 }

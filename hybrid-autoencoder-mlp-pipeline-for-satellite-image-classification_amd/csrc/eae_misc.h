@@ -46,14 +46,14 @@ int eae_launch_bn_bwd_coef(hipStream_t st, const double* sums, int C, long long 
 struct GateArgs { unsigned* word[4]; unsigned want[4]; int n; unsigned* timeout; unsigned long long limit_ticks; };
 int eae_launch_gate(hipStream_t st, const GateArgs& g);
 int eae_launch_signal(hipStream_t st, unsigned* word, unsigned val);
-int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base, Fp8State* q = nullptr);
+int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base, Fp8State* q = nullptr, unsigned* clear_word = nullptr);
 int eae_launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
                     double eps, double wd, long long step);
 int eae_launch_adam_dyn(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double b1, double b2, double eps,
-                        const float* dyn, const unsigned* bad = nullptr, float* nan_out = nullptr);
+                        const float* dyn, const unsigned* bad = nullptr, const unsigned* bad2 = nullptr, float* nan_out = nullptr);
 int eae_launch_set_dyn(hipStream_t st, float* dyn, double lr, double b1, double b2, double wd, long long step);
 int eae_launch_adam_scaled(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
                            double eps, double wd, long long step, float gscale, void* zero_buf = nullptr, long long zero_bytes = 0,
-                           const unsigned* bad = nullptr, float* nan_out = nullptr);
+                           const unsigned* bad = nullptr, const unsigned* bad2 = nullptr, float* nan_out = nullptr);
 int eae_launch_augment(hipStream_t st, const void* in_u8, float* out, int B, int H, int W, int train, float std, unsigned long long seed,
                        unsigned long long step, const int* params, const float* noise);

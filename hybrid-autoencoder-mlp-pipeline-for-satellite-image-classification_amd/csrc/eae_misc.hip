@@ -270,7 +270,8 @@ __device__ __forceinline__ float pack_fetch(const PackDesc& d, const float* __re
 }
 
 __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc* __restrict__ descs, const float* __restrict__ params,
-                                                        uint8_t* __restrict__ pack_base, Fp8State* __restrict__ q) {
+                                                        uint8_t* __restrict__ pack_base, Fp8State* __restrict__ q, unsigned* __restrict__ clear_word) {
+  if (clear_word != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *clear_word = 0u;
   const PackDesc d = descs[blockIdx.y];
   const float* src = params + d.src_off;
   const unsigned count = (unsigned)d.count;
@@ -333,6 +334,39 @@ __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc*
     }
     return;
   }
+  if ((d.mode == PACK_FC_ROWMAJOR_KPERM || d.mode == PACK_FC_TRANS_KPERM) && !d.out_f32 && (d.d2 & 63) == 0 && (d.d1 & 63) == 0 && (d.d0 & 63) == 0 &&
+      (unsigned)d.d0 * ((unsigned)d.d1 / 64) * ((unsigned)d.d2 / 64) >= 1024u) {
+    // enc.fc's two layouts on the big shapes (256x256 inputs: 16.7 M weights, P = 256 positions): 64 x 64 tiles through LDS.
+    //   row-major form  dst[r][p*Cc + c] <- src[r][c*P + p]: for one r, a tile of 64 channels x 64 positions;
+    //   transposed form dst[p*Cc + c][r] <- src[r][c*P + p]: for one c, a tile of 64 rows x 64 positions.
+    // Either way the source is read in 256-byte runs along p and the destination written in 128-byte runs (the thread-per-(r, c)
+    // mapping below touches 64 source lines per load instruction: 256 us of the 2.1 ms config-5 step went into this kernel).
+    __shared__ float tile[64][65];
+    const unsigned R = (unsigned)d.d0, Cc = (unsigned)d.d1, P = (unsigned)d.d2, K = Cc * P, lv = (unsigned)d.lv;
+    const bool rowmajor = d.mode == PACK_FC_ROWMAJOR_KPERM;
+    const unsigned npc = P / 64, nA = rowmajor ? Cc / 64 : R / 64, nfix = rowmajor ? R : Cc, ntiles = nfix * nA * npc;
+    bf16_t* dst = reinterpret_cast<bf16_t*>(pack_base + d.dst_off);
+    for (unsigned tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+      const unsigned pc = tl % npc, ac = (tl / npc) % nA, fix = tl / (npc * nA);
+      const unsigned p0 = pc * 64, a0 = ac * 64;                 // a = channel (row-major form) or row (transposed form)
+      __syncthreads();
+#pragma unroll 4
+      for (unsigned k = 0; k < 16; ++k) {
+        const unsigned idx = threadIdx.x + 256u * k, pp = idx & 63u, ai = idx >> 6;
+        const unsigned r = rowmajor ? fix : a0 + ai, c = rowmajor ? a0 + ai : fix;
+        tile[ai][pp] = r < lv ? src[(size_t)r * K + (size_t)c * P + p0 + pp] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (unsigned k = 0; k < 16; ++k) {
+        const unsigned idx = threadIdx.x + 256u * k, ai = idx & 63u, pp = idx >> 6;
+        const size_t o = rowmajor ? (size_t)fix * K + (size_t)(p0 + pp) * Cc + a0 + ai
+                                  : ((size_t)(p0 + pp) * Cc + fix) * R + a0 + ai;
+        dst[o] = (bf16_t)f2bf(tile[ai][pp]);
+      }
+    }
+    return;
+  }
   if ((d.mode == PACK_FC_ROWMAJOR_KPERM || d.mode == PACK_FC_TRANS_KPERM) && (d.d2 & 3) == 0 && !d.out_f32) {
     // enc.fc's two layouts (k' = p*Cc + c <- k = c*P + p).  One thread per (row r, channel c) reads its P consecutive source floats
     // (whole cache lines, each read once) and writes them P rows apart; the lanes of a wave run over c (row-major form) or over r
@@ -363,8 +397,8 @@ __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc*
   }
 }
 
-int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base, Fp8State* q) {
-  hipLaunchKernelGGL(pack_all_kernel, dim3(256, ndesc), dim3(256), 0, st, descs_dev, params, (uint8_t*)pack_base, q);
+int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base, Fp8State* q, unsigned* clear_word) {
+  hipLaunchKernelGGL(pack_all_kernel, dim3(256, ndesc), dim3(256), 0, st, descs_dev, params, (uint8_t*)pack_base, q, clear_word);
   EAE_LAUNCH_CHECK();
   return 0;
 }
@@ -430,12 +464,13 @@ void eae_fp8_state_init(Fp8State* h) {
 __global__ EAE_NO_PK __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n4, float b1, float b2, float step_size,
                                                     float bc2_sqrt, float eps, float wd, float gscale, uint4* __restrict__ zbuf, long zn16,
-                                                    const unsigned* __restrict__ bad, float* __restrict__ nan_out) {
+                                                    const unsigned* __restrict__ bad, const unsigned* __restrict__ bad2, float* __restrict__ nan_out) {
   // side job: clear the BatchNorm statistics accumulators for the next step (every consumer of this step has finished)
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zn16; i += (long)gridDim.x * 256) zbuf[i] = make_uint4(0, 0, 0, 0);
   // a side-stream gate of this context has timed out at some point (sticky word): gradients may have been computed from stale
   // activations -- no update, and the step's loss scalars become NaN so that the run cannot go on unnoticed
-  if (bad != nullptr && __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+  if ((bad != nullptr && __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ||
+      (bad2 != nullptr && __hip_atomic_load(bad2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
     if (nan_out != nullptr && blockIdx.x == 0 && threadIdx.x < 3) nan_out[threadIdx.x] = __builtin_nanf("");
     return;
   }
@@ -464,8 +499,9 @@ __global__ EAE_NO_PK __launch_bounds__(256) void adam_kernel(float* __restrict__
 __global__ EAE_NO_PK __launch_bounds__(256) void adam_dyn_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n4, float b1, float b2, float eps,
                                                         const float* __restrict__ dyn, const unsigned* __restrict__ bad,
-                                                        float* __restrict__ nan_out) {
-  if (bad != nullptr && __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {     // see adam_kernel
+                                                        const unsigned* __restrict__ bad2, float* __restrict__ nan_out) {
+  if ((bad != nullptr && __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ||
+      (bad2 != nullptr && __hip_atomic_load(bad2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {     // see adam_kernel
     if (nan_out != nullptr && blockIdx.x == 0 && threadIdx.x < 3) nan_out[threadIdx.x] = __builtin_nanf("");
     return;
   }
@@ -492,12 +528,12 @@ __global__ EAE_NO_PK __launch_bounds__(256) void adam_dyn_kernel(float* __restri
 __global__ EAE_NO_PK void set_dyn_kernel(float* dyn, float a, float b, float c) { dyn[0] = a; dyn[1] = b; dyn[2] = c; }
 
 int eae_launch_adam_dyn(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double b1, double b2, double eps,
-                        const float* dyn, const unsigned* bad, float* nan_out) {
+                        const float* dyn, const unsigned* bad, const unsigned* bad2, float* nan_out) {
   if (n % 4) return eae_set_error(-2, "adam: arena length must be a multiple of 4");
   long n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adam_dyn_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4, (float)b1, (float)b2, (float)eps, dyn, bad, nan_out);
+  hipLaunchKernelGGL(adam_dyn_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4, (float)b1, (float)b2, (float)eps, dyn, bad, bad2, nan_out);
   EAE_LAUNCH_CHECK();
   return 0;
 }
@@ -515,14 +551,14 @@ int eae_launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v
 
 int eae_launch_adam_scaled(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
                            double eps, double wd, long long step, float gscale, void* zero_buf, long long zero_bytes,
-                           const unsigned* bad, float* nan_out) {
+                           const unsigned* bad, const unsigned* bad2, float* nan_out) {
   if (n % 4) return eae_set_error(-2, "adam: arena length must be a multiple of 4");
   double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
   long n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4, (float)b1, (float)b2, (float)(lr / bc1),
-                     (float)sqrt(bc2), (float)eps, (float)wd, gscale, (uint4*)zero_buf, (long)(zero_bytes / 16), bad, nan_out);
+                     (float)sqrt(bc2), (float)eps, (float)wd, gscale, (uint4*)zero_buf, (long)(zero_bytes / 16), bad, bad2, nan_out);
   EAE_LAUNCH_CHECK();
   return 0;
 }
