@@ -36,7 +36,7 @@ int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_fl
   a.ntiles = ntiles;
   a.tiles_per_block = (ntiles + slices - 1) / slices;
   slices = (ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
-  a.part = scratch;
+  a.part = slices == 1 ? dw : scratch;      // one slice: its "partial" is the result (same layout), no reduction launch
   a.nslices = slices;
   constexpr size_t smem = WgGeo<TW, TH, NI>::smem();
   void (*kern)(WgradArgs) = wgrad_s2_kernel<CS, CB, TW, TH, NI, SM, BM>;
@@ -49,6 +49,7 @@ int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_fl
   hipLaunchKernelGGL(kern, dim3(slices * nblk), dim3(WG_THREADS), smem, st, a);
   if (hook) hook->end(hook->user, st);
   EAE_LAUNCH_CHECK();
+  if (slices == 1) return 0;
   hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(sz / 4)), dim3(256), 0, st, scratch, slices, (long)(sz / 4), dw, 1.0f);
   EAE_LAUNCH_CHECK();
   return 0;
