@@ -108,7 +108,8 @@ def table(rnd, tag):
     gates = [(float(r["AverageNs"]) / 1e3, int(r["Calls"])) for n, r in rows.items() if "gate_kernel" in n]
     if gates:
         print(f"\n`gate_kernel` (excluded above): {gates[0][1]} launches, {gates[0][0]:.1f} µs average of one wave spinning.")
-    calls = [int(r["Calls"]) for n, r in rows.items() if "adam" in n and "kernel" in n]
+    # steps = launches of a once-per-step kernel (the fp8 calibration adds gradient steps without an optimizer step)
+    calls = [int(r["Calls"]) for n, r in rows.items() if "deconv4_loss_kernel" in n] or [int(r["Calls"]) for n, r in rows.items() if "adam" in n and "kernel" in n]
     if calls:
         steps = max(calls)
         line = f"\nSum of kernel durations per step (all streams, gates excluded): {tot / steps / 1e3:.0f} µs over {steps} steps"
