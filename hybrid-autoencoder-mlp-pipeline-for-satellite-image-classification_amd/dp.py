@@ -19,6 +19,7 @@ the fp64 sums), so that R ranks x B/R images reproduce one rank x B images; the 
 from __future__ import annotations
 
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -95,7 +96,39 @@ class DataParallelTrainer:
         if native is None:
             native = os.environ.get("EAE_DP_NATIVE", "1") == "1"
         if native and hasattr(engine, "ctx") and dist.get_backend(process_group) == "nccl":
+            self._init_native_checked()
+
+    def _init_native_checked(self):
+        """Join the engine's communicator, then prove it on a known vector (rank r contributes r + 1 to 64 gradient words) before it is
+        trusted with real gradients.  Every rank learns whether EVERY rank succeeded (one torch all-reduce of a flag): on any failure
+        all ranks fall back to the torch.distributed exchange together -- a half-native group would hang in its first collective."""
+        import ctypes as C
+        from .engine import _stream
+        eng = self.eng
+        ok, why = 1, ""
+        try:
             self._init_native()
+            keep = eng.grads[:64].clone()
+            eng.grads[:64] = float(self.rank + 1)
+            with torch.cuda.device(eng.device):
+                rc = int(eng.lib.eae_dp_allreduce_bucket(eng.ctx, _stream(), C.c_longlong(0), C.c_longlong(64)))
+            torch.cuda.synchronize(eng.device)
+            want = self.world * (self.world + 1) / 2.0
+            if rc != 0 or not bool((eng.grads[:64] == want).all()):
+                ok, why = 0, f"self-check of the engine's all-reduce failed (rc {rc}, got {float(eng.grads[0])}, want {want})"
+            eng.grads[:64] = keep
+        except Exception as e:      # a missing librccl symbol, a refused communicator, ...
+            ok, why = 0, f"{type(e).__name__}: {e}"
+        flag = torch.tensor([ok], dtype=torch.int32, device=eng.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+        if int(flag.item()) != 1:
+            if why:
+                print(f"[eae dp] rank {self.rank}: engine-owned RCCL exchange unavailable ({why}); using torch.distributed", file=sys.stderr, flush=True)
+            try:
+                eng.lib.eae_dp_destroy(eng.ctx)
+            except Exception:
+                pass
+            self.native = False
 
     def _init_native(self):
         import ctypes as C
