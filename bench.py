@@ -165,7 +165,7 @@ def grid_b64_leg(k=int(os.environ.get("EAE_GRID_K", "4")), steps=150, warmup=15)
     from eae_amd.engine import engine_for
     from eae_amd import train as T
     res = {"workload": "BASELINE configs[2]'s step at the notebook's batch size 64 (R.md:246): K independent (alpha, lr) configurations of "
-                       "the grid R.md:599-711 trained concurrently on one GPU, one engine context + stream + host thread each", "batch": 64}
+                       "the grid R.md:599-711 trained concurrently on one GPU, one engine context + ONE stream + host thread each", "batch": 64}
     x, y = make_batch(64, torch.device("cuda"), seed=4321)
     graph = os.environ.get("EAE_GRID_GRAPH", "0") == "1"      # replay measured slower than eager here (0.7-0.8x): see train.grid_search_autoencoder
     res["graph_replay"] = graph
@@ -174,6 +174,8 @@ def grid_b64_leg(k=int(os.environ.get("EAE_GRID_K", "4")), steps=150, warmup=15)
         for i in range(kk):
             torch.manual_seed(100 + i)
             m = eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=10).cuda().train()
+            if kk >= 3:
+                m._eae_side_streams = -1          # what grid_search_autoencoder(concurrent >= 3) does: one stream per context
             e = engine_for(m, max_batch=64)
             e.set_graph(graph and kk > 1)         # K concurrent configurations are bound by the host's launch rate: one replay per step
             engs.append((m, e))

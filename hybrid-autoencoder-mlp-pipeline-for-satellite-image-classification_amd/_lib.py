@@ -14,7 +14,7 @@ vp = C.c_void_p
 
 class EaeConfig(C.Structure):
     _fields_ = [("latent_dim", C.c_int), ("num_classes", C.c_int), ("image_h", C.c_int), ("image_w", C.c_int),
-                ("max_batch", C.c_int), ("quant", C.c_int)]
+                ("max_batch", C.c_int), ("quant", C.c_int), ("side_streams", C.c_int)]
 
 
 class EaeStepIO(C.Structure):

@@ -233,6 +233,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   {
     const char* e = getenv("EAE_SIDE_STREAMS");
     int ns = e ? atoi(e) : 2;
+    if (cfg->side_streams > 0) ns = cfg->side_streams;
     c->nx = ns < 1 ? 0 : (ns - 1 > eae_ctx::MAXX ? eae_ctx::MAXX : ns - 1);
     if (getenv("EAE_ONE_SIDE_STREAM")) c->nx = 0;
   }
@@ -349,7 +350,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->fold_fwd = getenv("EAE_NO_FOLD_FWD") == nullptr;
   c->fold_bwd = getenv("EAE_NO_FOLD_BWD") == nullptr;
   if (e != hipSuccess) { hipFree(c->ws); delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
-  c->use_side = getenv("EAE_NO_SIDE_STREAM") == nullptr;
+  c->use_side = getenv("EAE_NO_SIDE_STREAM") == nullptr && cfg->side_streams >= 0;
   if (c->use_side) {
     // Side work only feeds the optimizer.  Lowest stream priority (EAE_SIDE_PRIO_LOW=1) lets the dependency chain on the
     // caller's stream win the CUs (-7 us/step at B=512), but it is not the default: whenever only low-priority queues had
@@ -1292,7 +1293,7 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
   RC(check_io(c, io, true));
   if (!c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: moment arenas must be bound");
   hipStream_t user = (hipStream_t)stream, st = user;
-  const bool graph_ok = c->use_graph && c->use_side && !c->prof_on && !c->packed && io->logits == nullptr && io->z == nullptr;
+  const bool graph_ok = c->use_graph && (c->use_side || user != nullptr) && !c->prof_on && !c->packed && io->logits == nullptr && io->z == nullptr;
   if (graph_ok && user == nullptr) {      // legacy default stream: run on the engine's own stream, ordered by events
     st = c->own_main;
     EAE_HIP(hipEventRecord(c->ev_in, user));

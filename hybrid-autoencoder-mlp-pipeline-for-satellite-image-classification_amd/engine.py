@@ -50,7 +50,7 @@ def _require_gpu(device):
 class AEEngine:
     """Owns the arenas + C context of one SupervisedAutoencoder (or a stand-alone Encoder / Decoder)."""
 
-    def __init__(self, root, max_batch=512, quant=None):
+    def __init__(self, root, max_batch=512, quant=None, side_streams=None):
         from .modules import SupervisedAutoencoder, Encoder, Decoder
         self.quant = {None: 0, "bf16": 0, "fp8": 1, 0: 0, 1: 1}[quant]
         self.lib = _lib.load()
@@ -68,7 +68,10 @@ class AEEngine:
         p0 = next(root.parameters())
         self.device = p0.device
         _require_gpu(self.device)
-        self.cfg = EaeConfig(latent, classes, size, size, int(max_batch), self.quant)
+        # side_streams: None / 0 = the engine's default (two side streams), 1 / 2 = that many, -1 = none (one stream per context: what
+        # several contexts stepped concurrently want, include/eae.h eae_config.side_streams)
+        self.side_streams = int(side_streams or 0)
+        self.cfg = EaeConfig(latent, classes, size, size, int(max_batch), self.quant, self.side_streams)
         self.max_batch = int(max_batch)
         poff = (C.c_longlong * 39)()
         boff = (C.c_longlong * 15)()
@@ -373,7 +376,8 @@ def _engine_for_locked(module, max_batch, quant):
     elif eng is not None and eng.max_batch < want_mb:
         old, eng = eng, None     # same parameters, bigger workspace: the optimizer state moves to the new engine
     if eng is None:
-        eng = AEEngine(root, max_batch=want_mb, quant=quant if old is None else old.quant)
+        eng = AEEngine(root, max_batch=want_mb, quant=quant if old is None else old.quant,
+                       side_streams=getattr(root, "_eae_side_streams", None) if old is None else old.side_streams)
         if old is not None:
             with torch.no_grad():
                 eng.adam_m.copy_(old.adam_m)

@@ -40,6 +40,8 @@ def ce_mse_ratio_probe(batches, n_models=1000, latent_dim=128, num_classes=10, d
     for j in range(k):                 # trial j's parameters are the constructor's own draws (trials 0..k-1, in order)
         model = SupervisedAutoencoder(latent_dim=latent_dim, num_classes=num_classes).to(device)
         model.train()
+        if k >= 3:
+            model._eae_side_streams = -1       # one stream per context: four contexts then run side by side (4 hardware queues)
         pairs.append(model)
 
     def batch_for(i):

@@ -85,13 +85,15 @@ def _first_batch_size(loader, default=64):
 
 # ------------------------------------------------------------------------------------------------ autoencoder
 def fit_autoencoder(train_loader, val_loader, alpha, lr, latent_dim=64, num_classes=10, num_epochs=80, patience=15,
-                    device="cuda", model=None, stepper=None, head=True, verbose=True, log=print, graph=None):
+                    device="cuda", model=None, stepper=None, head=True, verbose=True, log=print, graph=None, side_streams=None):
     """One (alpha, lr) configuration of the reference's AE loop (R.md:619-697).
 
     Returns dict(model, train_curve, val_curve, best_val_loss, epochs).  As in the reference, `model` holds the weights of
     the LAST epoch run (R.md:705 keeps a live reference, not the best epoch's weights)."""
     if model is None and stepper is None:
         model = SupervisedAutoencoder(latent_dim=latent_dim, num_classes=num_classes).to(device)
+        if side_streams is not None:
+            model._eae_side_streams = side_streams      # read when the model's engine is first built (engine.engine_for)
     if stepper is None:
         stepper = AEStepper(model, alpha, lr, head=head, graph=graph,
                             max_batch=max(_first_batch_size(train_loader), _first_batch_size(val_loader)))
@@ -179,11 +181,11 @@ def grid_search_autoencoder(train_loader, val_loader, alpha_values=(20, 25, 30, 
         def job_of(alpha, lr):
             def job():
                 lines = []
-                # (measured on MI355X at B=64, tools + bench.py `configs.grid_b64`: K = 4 / 8 / 16 eager configurations reach 1.6-1.7x the
-                #  single-configuration rate and then saturate at ~310 K kernel dispatches per second over all queues; hipGraph replay of
-                #  each step -- AEStepper(graph=True) -- removes the host from the loop and is SLOWER, 0.7-0.8x of eager: the limit is the
-                #  command processor's dependent-dispatch rate, i.e. the ~57 launches of a step, not the host)
-                extra = {}
+                # Measured on MI355X at B=64 (bench.py `configs.grid_b64`): a process reaches the GPU through 4 hardware
+                # queues.  Contexts with the default three streams each share them -- K = 2 / 4 / 8 / 16 reach 1.65x the single-configuration
+                # rate and stay there -- while ONE stream per context lets four configurations run side by side: 487 K vs 352 K images/s
+                # at K = 4.  hipGraph replay of each step is slower than eager (0.7-0.8x), more hardware queues or several processes far slower.
+                extra = {"side_streams": -1} if (int(concurrent) >= 3 and fit_fn is fit_autoencoder) else {}
                 r = fit_fn(train_loader, val_loader, alpha, lr, latent_dim=latent_dim, num_epochs=num_epochs, patience=patience,
                            device=device, verbose=verbose, log=lines.append, **extra)
                 r = dict(r)

@@ -60,9 +60,11 @@ def test_concurrent_steps_from_threads_scale_and_stay_deterministic():
     x, y = gu.make_images(64, 77)
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
 
-    def make(i):
+    def make(i, single_stream=False):
         torch.manual_seed(50 + i)
         m = eae_amd.SupervisedAutoencoder(64).cuda().train()
+        if single_stream:
+            m._eae_side_streams = -1        # eae_config.side_streams = -1: what grid_search_autoencoder(concurrent >= 3) builds
         return m, engine_for(m, max_batch=64)
 
     ref = []
@@ -72,7 +74,10 @@ def test_concurrent_steps_from_threads_scale_and_stay_deterministic():
             e.train_step(xd, yd, 35.0, 1e-3)
         torch.cuda.synchronize()
         ref.append(e.params.clone())
-    pairs = [make(i) for i in range(4)]
+    # the concurrent contexts keep every kernel on their ONE stream (four hardware queues: four contexts side by side); the reference
+    # runs above used the default three streams per context -- same bits either way
+    pairs = [make(i, single_stream=True) for i in range(4)]
+    assert all(e.side_streams == -1 for _, e in pairs)
 
     def job_of(e):
         def job():
@@ -86,3 +91,39 @@ def test_concurrent_steps_from_threads_scale_and_stay_deterministic():
     assert touts == [0, 0, 0, 0]
     for i, (_, e) in enumerate(pairs):
         assert torch.equal(e.params, ref[i]), i
+
+
+@pytest.mark.parametrize("b", [8, 64, 512])
+def test_single_stream_context_is_bitwise_the_default_one(b):
+    """eae_config.side_streams = -1 (every kernel on the caller's stream, in dependency order): the same losses, gradients and
+    parameters, bit for bit, as the default context with its two side streams -- joint steps, a reconstruction-only step, and the
+    gradient-only entry point."""
+    import eae_amd
+    from eae_amd.engine import engine_for
+    x, y = gu.make_images(b, 4100 + b)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    out = []
+    for single in (False, True):
+        torch.manual_seed(321)
+        m = eae_amd.SupervisedAutoencoder(64).cuda().train()
+        if single:
+            m._eae_side_streams = -1
+        e = engine_for(m, max_batch=b)
+        assert e.side_streams == (-1 if single else 0)
+        losses = []
+        for step in range(3):
+            e.train_step(xd, yd, 35.0, 2e-3)
+            losses.append(e.loss_last.cpu().numpy().copy())
+        e.train_step(xd, yd, 1.0, 2e-3, head=False)
+        losses.append(e.loss_last.cpu().numpy().copy())
+        e.grad_step(xd, yd, 35.0)
+        torch.cuda.synchronize()
+        assert e.gate_timeouts() == 0
+        out.append((np.stack(losses), e.grads.cpu().numpy().copy(), e.params.cpu().numpy().copy(),
+                    {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}))
+    a, c = out
+    assert np.array_equal(a[0], c[0]), (a[0], c[0])
+    assert np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2])
+    for k in a[3]:
+        assert np.array_equal(a[3][k], c[3][k]), k
+    assert np.isfinite(a[0]).all() and np.abs(a[1]).max() > 0
