@@ -97,3 +97,25 @@ def test_bench_line_contract_and_roofline_arithmetic():
     assert prof["summary_commit"]
     # the live duration and the committed rocprofv3 average of the same kernel agree (tracing changes how the streams line up)
     assert 0.6 <= rf["avg_launch_us"] / prof["rocprof_avg_us"] <= 1.4, (rf["avg_launch_us"], prof["rocprof_avg_us"])
+
+
+@pytest.mark.gpu
+def test_bench_side_workload_line_carries_its_own_roofline():
+    """`bench.py --workload c2` (what tools/profile_round.sh profiles for BASELINE configs[1]): one JSON line, the metric's contract,
+    the workload named, and a roofline object priced for THAT workload (its own committed summary, its own batch)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["unit"] == "images/s" and d["dtype"] == "bf16" and "configs[1]" in d["config"]["workload"]
+    assert d["config"]["per_gpu_batch"] == 256 and abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-4
+    from eae_amd import profile_hooks as ph
+    role, bpi, mf = ph.site_model(rf["site"], 64, 64)
+    assert rf["algorithmic_bytes_per_launch"] == 256 * bpi and ph.site_of(rf["kernel"]) == rf["site"]
+    prof = rf["from_committed_profile"]
+    assert prof["summary"].startswith("profiles/r03_bench_c2_") and prof["summary_commit"]
+    assert rf["traffic"] == prof["pmc_traffic_bytes_per_launch"]
