@@ -225,27 +225,28 @@ __device__ __forceinline__ double lf_wave_sum(double v) {
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-constexpr int LF_THREADS = 1024;
-__global__ EAE_NO_PK __launch_bounds__(LF_THREADS) void loss_finalize_kernel(const float* mse_part, int n_mse, const float* ce_part, int n_ce, float alpha,
+__global__ EAE_NO_PK __launch_bounds__(256) void loss_finalize_kernel(const float* mse_part, int n_mse, const float* ce_part, int n_ce, float alpha,
                                                              float inv_numel, float B, float* db4, float* accum, float* last, const unsigned* poison) {
-  __shared__ double red[LF_THREADS / 64][6];
+  __shared__ double red[4][6];
   const int tid = threadIdx.x;
   double s[6] = {0, 0, 0, 0, 0, 0};
-  // ONE block of 16 waves, 8 loads in flight per thread: at B=512 (4096 partial rows) every row is requested in the first round.
-  // (round 2: one load per iteration = 16 dependent round trips, 16 us; round 3: 256 threads x 8 = two rounds, 11 us)
-  for (int i0 = tid; i0 < n_mse; i0 += LF_THREADS * 8) {
+  // 8 loads in flight per thread: with one load per loop iteration every iteration exposed a full memory round trip (16 of them at
+  // B=512: that, not the reduction, was this kernel's 16 us)
+  // (ONE 1024-thread block with every row requested in the first round was measured too: 29 us in situ instead of 11 -- a 16-wave
+  //  workgroup waits for a CU with that many free wave slots beside the register-filling weight-gradient workgroups)
+  for (int i0 = tid; i0 < n_mse; i0 += 256 * 8) {
     float4 v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int i = i0 + q * LF_THREADS;
+      const int i = i0 + q * 256;
       v[q] = i < n_mse ? reinterpret_cast<const float4*>(mse_part)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) { s[0] += v[q].x; s[1] += v[q].y; s[2] += v[q].z; s[3] += v[q].w; }
   }
-  for (int i = tid; i < n_ce; i += LF_THREADS) { s[4] += ce_part[i * 2]; s[5] += ce_part[i * 2 + 1]; }
+  for (int i = tid; i < n_ce; i += 256) { s[4] += ce_part[i * 2]; s[5] += ce_part[i * 2 + 1]; }
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < 6; ++k) {       // (round 2: a 9-step LDS tree with 8 barriers over fp64[256][6], 16-18 us inside the step)
     const double w = lf_wave_sum(s[k]);
     if ((tid & 63) == 0) red[tid >> 6][k] = w;
   }
@@ -253,11 +254,7 @@ __global__ EAE_NO_PK __launch_bounds__(LF_THREADS) void loss_finalize_kernel(con
   if (tid == 0) {
     double r[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      double t = red[0][k];
-      for (int w = 1; w < LF_THREADS / 64; ++w) t += red[w][k];      // fixed order: bitwise reproducible
-      r[k] = t;
-    }
+    for (int k = 0; k < 6; ++k) r[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
     float mse = (float)(r[0] * inv_numel);
     float cem = n_ce ? (float)(r[4] / B) : 0.f;
     float loss = alpha * mse + cem;
@@ -271,7 +268,7 @@ __global__ EAE_NO_PK __launch_bounds__(LF_THREADS) void loss_finalize_kernel(con
 
 int eae_launch_loss_finalize(hipStream_t st, const float* mse_part, int n_mse, const float* ce_part, int n_ce, float alpha,
                              double numel, int B, float* db4, float* accum, float* last, const unsigned* poison) {
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(LF_THREADS), 0, st, mse_part, n_mse, ce_part, n_ce, alpha,
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, mse_part, n_mse, ce_part, n_ce, alpha,
                      (float)(1.0 / numel), (float)B, db4, accum, last, poison);
   EAE_LAUNCH_CHECK();
   return 0;
