@@ -123,6 +123,8 @@ struct eae_ctx {
   size_t poison_off = 0;       // byte offset of the step-wide non-finite word inside the accumulator region (cleared with it)
   size_t acc_bytes = 0;
   bool acc_clean = false;          // all zero (cleared by the engine's own Adam launch or at creation)
+  bool bwd_dirty = false;          // the BACKWARD half of the accumulators holds the sums of an earlier backward (no clear since)
+  size_t acc_half = 0;             // byte offset of the backward half inside the accumulator region
   // synchronized BatchNorm across data-parallel replicas (eae_set_sync_bn): the batch statistics of every BN layer are summed
   // over the replicas through the caller's hook (forward: the fixed-point accumulators; backward: the fp64 sums) before the
   // consumers turn them into coefficients with the GLOBAL element count
@@ -315,7 +317,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   }
   for (int l = 0; l < 7; ++l) { c->coef_f[l] = (float*)(b + o_cf[l]); c->coef_b[l] = (float*)(b + o_cb[l]); }
   c->stat = (float*)(b + o_stat); c->wscratch = (float*)(b + o_wscr); c->wscratch_main = (float*)(b + o_wscrm);
-  c->acc_base = b + o_accb; c->poison_off = (2 * acc_total + 15) & ~(size_t)15; c->acc_bytes = c->poison_off + 16;      // + the step-wide poison word
+  c->acc_base = b + o_accb; c->poison_off = (2 * acc_total + 15) & ~(size_t)15; c->acc_bytes = c->poison_off + 16; c->acc_half = acc_total;      // + the step-wide poison word
   for (int l = 0; l < 7; ++l) c->accf[l] = (unsigned long long*)(b + o_accb + o_acc[l]);
   for (int l = 0; l < 7; ++l) c->accb[l] = (unsigned long long*)(b + o_accb + acc_total + o_acc[l]);
   for (int i = 0; i < c->nx; ++i) c->wscratchx[i] = (float*)(b + o_wscrx[i]); c->fcpart = (float*)(b + o_fcp);
@@ -346,7 +348,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   if (e == hipSuccess) e = hipMemset(c->dz, 0, Bm * (size_t)c->Lp * 4);
   if (e == hipSuccess) e = hipMemset(c->acc_base, 0, c->acc_bytes);
   if (e == hipSuccess) e = hipMemset(c->sigwords, 0, 64);
-  c->acc_clean = true;
+  c->acc_clean = true; c->bwd_dirty = false;
   c->fold_fwd = getenv("EAE_NO_FOLD_FWD") == nullptr;
   c->fold_bwd = getenv("EAE_NO_FOLD_BWD") == nullptr;
   if (e != hipSuccess) { hipFree(c->ws); delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
@@ -708,8 +710,18 @@ void fold_consumer(eae_ctx* c, BnFold& f, int l, long long count, bool train) {
 // as a side job, any other sequence (forward only, external optimizer, encoder / decoder alone) pays one memset here
 int prep_accumulators(eae_ctx* c, hipStream_t st, bool train) {
   if (!train || !c->fold_fwd) return 0;
-  if (!c->acc_clean || c->capturing) EAE_HIP(hipMemsetAsync(c->acc_base, 0, c->acc_bytes, st));   // a captured step always carries it
+  if (!c->acc_clean || c->capturing) { EAE_HIP(hipMemsetAsync(c->acc_base, 0, c->acc_bytes, st)); c->bwd_dirty = false; }   // a captured step always carries it
   c->acc_clean = false;
+  return 0;
+}
+// ... and the BACKWARD accumulators when its producers start.  A train-mode forward with the folded finalize has just cleared the
+// whole region (or the optimizer kernel did); what is left are the sequences that reach a backward without either: eval-mode
+// backward after eval-mode backward (autograd with frozen statistics and an external optimizer), EAE_NO_FOLD_FWD -- their sums
+// used to pile up (found by the EAE_NO_FOLD_FWD x fp8-calibration sweep: 8 gradient steps, gradients 92x too large)
+int prep_bwd_accumulators(eae_ctx* c, hipStream_t st) {
+  if (!c->fold_bwd) return 0;
+  if (c->bwd_dirty) EAE_HIP(hipMemsetAsync(c->acc_base + c->acc_half, 0, c->poison_off - c->acc_half, st));
+  c->bwd_dirty = true; c->acc_clean = false;
   return 0;
 }
 
@@ -949,6 +961,9 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
 // part 0 = everything, 1 = classifier + decoder + dec.fc (gradient tensors 18..37), 2 = enc.fc + encoder (tensors 0..17)
 int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float* dz_ext = nullptr, int part = 0) {
   const int B = io->B, H = c->H, W = c->W;
+  // (part 2 = the encoder half: behind part 1 of a split backward -- whose side-stream consumers may still be reading the decoder
+  //  layers' sums -- nothing is cleared; the stand-alone encoder backward clears before it calls)
+  if (part != 2) RC(prep_bwd_accumulators(c, st));
   if (c->prebn_dirty && !c->bwd_eval) {      // train mode again: those biases have an identically zero gradient, never written
     for (int k = 0; k < 7; ++k)
       EAE_HIP(hipMemsetAsync(c->G + c->poff[PREBN_BIAS[k]], 0, (size_t)(c->poff[PREBN_BIAS[k] + 1] - c->poff[PREBN_BIAS[k]]) * 4, st));
@@ -1245,7 +1260,7 @@ extern "C" int eae_adam_step(eae_ctx* c, void* stream, float lr, float weight_de
   c->adam_step += 1;
   RC(eae_launch_adam_scaled((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step, 1.0f,
                             c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss));
-  c->packed = false; c->acc_clean = true;
+  c->packed = false; c->acc_clean = true; c->bwd_dirty = false;
   return 0;
 }
 
@@ -1282,7 +1297,7 @@ extern "C" int eae_adam_step_scaled(eae_ctx* c, void* stream, float lr, float we
   c->adam_step += 1;
   RC(eae_launch_adam_scaled((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step, grad_scale,
                             c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss));
-  c->packed = false; c->acc_clean = true;
+  c->packed = false; c->acc_clean = true; c->bwd_dirty = false;
   return 0;
 }
 
@@ -1293,7 +1308,7 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
   RC(check_io(c, io, true));
   if (!c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: moment arenas must be bound");
   hipStream_t user = (hipStream_t)stream, st = user;
-  const bool graph_ok = c->use_graph && (c->use_side || user != nullptr) && !c->prof_on && !c->packed && io->logits == nullptr && io->z == nullptr;
+  const bool graph_ok = c->use_graph && (c->use_side || user != nullptr) && c->fold_fwd && c->fold_bwd && !c->prof_on && !c->packed && io->logits == nullptr && io->z == nullptr;
   if (graph_ok && user == nullptr) {      // legacy default stream: run on the engine's own stream, ordered by events
     st = c->own_main;
     EAE_HIP(hipEventRecord(c->ev_in, user));
@@ -1316,7 +1331,7 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
     if (!rc) rc = backward_impl(c, st, io);
     if (!rc) rc = eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f,
                                          c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss);
-    c->packed = false; c->acc_clean = (rc == 0);
+    c->packed = false; c->acc_clean = (rc == 0); c->bwd_dirty = !c->acc_clean;
     return rc;
   }
   RC(eae_launch_set_dyn(st, c->dyn, lr, 0.9, 0.999, 0.0, c->adam_step));
@@ -1382,6 +1397,7 @@ extern "C" int eae_encoder_backward(eae_ctx* c, void* stream, long long generati
   io.x = x; io.B = c->fwd_B; io.train = 1; io.head = 0;
   c->bwd_eval = c->enc_ready == 2;
   if (c->bwd_eval) c->prebn_dirty = true;
+  RC(prep_bwd_accumulators(c, st));            // (a stand-alone backward: backward_impl leaves part 2 alone)
   const int rc = backward_impl(c, st, &io, nullptr, 2);
   c->bwd_eval = false;
   c->enc_ready = 0;
@@ -1546,7 +1562,7 @@ extern "C" int eae_ae_dp_train_step(eae_ctx* c, void* stream, const eae_step_io*
   }
   RC(eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f / (float)c->dp_world,
                             c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss));
-  c->packed = false; c->acc_clean = true;
+  c->packed = false; c->acc_clean = true; c->bwd_dirty = false;
   return 0;
 }
 

@@ -5,6 +5,8 @@ Two references per quantity:
       path from SURVEY.md 8c: x_hat <= 3e-2 max-abs and <= 3e-3 mean-abs, logits / z <= 2 % of the tensor's abs-max;
   (2) the NumPy oracle with bf16 storage emulation (same rounding points as the kernels) -- tight tolerances.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -517,6 +519,7 @@ def test_autograd_drop_in_loop_matches_fused_step(golden):
     assert torch.isfinite(xh2).all()
 
 
+@pytest.mark.skipif(bool(os.environ.get("EAE_NO_FOLD_BWD")), reason="the eval-mode backward is built on the folded BatchNorm-backward finalize")
 def test_autograd_through_an_eval_mode_model_vs_torch_cpu_port(golden):
     """`model.eval(); loss.backward()` (fine-tuning with frozen BatchNorm statistics): BatchNorm normalises with the running
     statistics and is differentiated as the per-channel affine map it then is.  Gradients against torch autograd of the torch-CPU
@@ -554,6 +557,15 @@ def test_autograd_through_an_eval_mode_model_vs_torch_cpu_port(golden):
         if not (c > 0.97 and 0.9 <= ratio <= 1.1):
             bad.append((name, round(c, 4), round(float(ratio), 3)))
     assert not bad, bad
+    # a SECOND eval-mode backward right behind the first (fine-tuning with an external optimizer: no engine-side Adam in between that
+    # would clear the BatchNorm-backward accumulators): the same gradients, bit for bit -- the sums of the first pass must not pile up
+    first = {name: prm.grad.detach().clone() for name, prm in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    xh2, lg2, _ = m(_cuda(x))
+    (alpha * nn.MSELoss()(xh2, _cuda(x)) + nn.CrossEntropyLoss()(lg2, _cuda(y))).backward()
+    torch.cuda.synchronize()
+    for name, prm in m.named_parameters():
+        assert torch.equal(prm.grad, first[name]), name
     # a train-mode gradient step afterwards: the biases in front of the BatchNorms have an identically zero gradient again
     eng = _engine(m)
     eng.grad_step(_cuda(x), _cuda(y), alpha)
@@ -885,14 +897,20 @@ def test_non_finite_input_poisons_the_step_like_the_reference():
 
 
 def _stall(seconds):
-    """Keep the CURRENT stream busy for about `seconds` (torch.cuda._sleep spins for a number of device clock ticks: calibrated here)."""
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    """Keep the CURRENT stream busy for about `seconds`: many short torch.cuda._sleep kernels (it spins for a number of shader-clock
+    ticks: one long count overflows its 32-bit counter, and a single calibration taken on an idle, down-clocked GPU is several times
+    too long -- the probe is timed three times after a warm-up and the SHORTEST is used, so the stall is at least as long as asked)."""
     probe = 20_000_000
+    torch.cuda._sleep(probe); torch.cuda._sleep(probe)
     torch.cuda.synchronize()
-    e0.record(); torch.cuda._sleep(probe); e1.record()
-    torch.cuda.synchronize()
-    per_probe = max(e0.elapsed_time(e1) * 1e-3, 1e-4)      # seconds one probe-sized sleep takes on this box
-    for _ in range(int(seconds / per_probe) + 1):           # (many short sleeps: one long tick count overflows the kernel's 32-bit counter)
+    times = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); torch.cuda._sleep(probe); e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) * 1e-3)
+    per_probe = max(min(times), 1e-4)
+    for _ in range(min(int(seconds / per_probe) + 1, 20000)):
         torch.cuda._sleep(probe)
 
 
@@ -917,6 +935,7 @@ def test_caller_stream_stalled_for_seconds_in_front_of_a_step_is_waited_for():
     assert torch.equal(ea.grads, eb.grads)
 
 
+@pytest.mark.skipif(bool(os.environ.get("EAE_NO_SIDE_STREAM") or os.environ.get("EAE_FORK_EVENTS")), reason="event hand-overs / no side streams: nothing is gated")
 def test_a_gate_timeout_is_loud(monkeypatch):
     """... and a gate that does time out (bound lowered to 100 ms for this context) cannot go unnoticed: the sticky word makes the
     optimizer kernel leave the parameters untouched and write NaN losses, check_gates() / AEStepper.end() raise."""
