@@ -107,6 +107,81 @@ def test_dp_world2_gloo(tmp_path):
     assert os.path.exists(tmp_path / "ok")
 
 
+class _FakeLib:
+    """libeae stand-in for the communicator entry points: rank `fail_rank` cannot join (raises like a missing librccl symbol would)."""
+
+    def __init__(self, rank, fail_rank):
+        self.rank, self.fail_rank, self.destroyed = rank, fail_rank, False
+
+    def eae_dp_world(self, ctx):
+        return 0
+
+    def eae_dp_unique_id(self, buf):
+        return 0
+
+    def eae_dp_init(self, ctx, rank, world, raw):
+        if rank == self.fail_rank:
+            return -5
+        return 0
+
+    def eae_dp_allreduce_bucket(self, ctx, stream, off, count):
+        return 0
+
+    def eae_dp_destroy(self, ctx):
+        self.destroyed = True
+        return 0
+
+    def eae_last_error(self):
+        return b"simulated: ncclCommInitRank failed"
+
+
+def _worker_fallback(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from eae_amd import dp, _lib
+        eng = OracleEngine(seed=7)
+        eng.ctx, eng.device = object(), torch.device("cpu")
+        eng.lib = _FakeLib(rank, fail_rank=1)
+        _lib.load = lambda: eng.lib                          # check() reads the error text through the loaded library
+        real_backend = dist.get_backend
+        dist.get_backend = lambda group=None: "nccl"         # take the native branch (the collectives underneath stay gloo)
+        try:
+            tr = dp.DataParallelTrainer(eng, native=True)
+        finally:
+            dist.get_backend = real_backend
+        # rank 1 could not join; rank 0 could (its self-check fails later on the CPU stand-in anyway): BOTH must have left the native
+        # path, or the first collective of a half-native group would hang
+        assert tr.native is False and tr.rccl_ranks() == 0 and eng.lib.destroyed
+        flags = [torch.zeros(1) for _ in range(world)]
+        dist.all_gather(flags, torch.tensor([0.0 if tr.native else 1.0]))
+        assert all(float(f) == 1.0 for f in flags)
+        # ... and the torch.distributed exchange works from there
+        import golden_util as gu
+        tr.broadcast_parameters(src=0)
+        x, y = gu.make_images(4, 901)
+        tr.train_step(torch.from_numpy(x[rank * 2:(rank + 1) * 2]), torch.from_numpy(y[rank * 2:(rank + 1) * 2]), 35.0, 1e-3)
+        mine = eng.params.clone()
+        other = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(other, mine)
+        assert torch.equal(other[0], other[1])
+        if rank == 0:
+            open(os.path.join(tmp, "ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_native_exchange_failure_on_one_rank_makes_every_rank_fall_back(tmp_path):
+    """dp.DataParallelTrainer joins the engine-owned RCCL communicator and proves it on a known vector; if ANY rank fails, ALL ranks
+    must take the torch.distributed path (agreed through one all-reduce of a flag).  Two gloo ranks, a libeae stand-in whose
+    eae_dp_init fails on rank 1 only."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_fallback, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok")
+
+
 def test_bucket_bounds_cover_arena():
     from eae_amd import dp
     offs = list(range(0, 39 * 8, 8))
