@@ -1170,3 +1170,46 @@ def test_config5_benchmarked_geometry_b128_properties():
     nr = np.linalg.norm(gf.astype(np.float64)) / np.linalg.norm(gb.astype(np.float64))
     assert G.cosine(gf, gb) > 0.95 and 0.88 <= nr <= 1.12, (G.cosine(gf, gb), nr)         # (3)
     assert abs(got["fp8"][1] - got["bf16"][1]) <= 3e-2 * abs(got["bf16"][1])
+
+
+def test_training_curve_tracks_the_torch_cpu_port_over_120_steps():
+    """Training DYNAMICS, not one step: 120 joint steps (4 batches of 64 learnable images cycled 30 times, alpha 35, lr 1e-3) on the
+    engine and on the fp32 torch-CPU port of the reference graph from the same initial weights.  Per-step trajectories of a bf16 and an
+    fp32 run diverge element-wise (chaos), the LOSS curves must not: the mean loss of every 20-step window within 4 % of the port's,
+    both fall by more than a third, and the final validation loss (eval mode: running statistics) of the two models within 5 %."""
+    from oracle import ae_torch_cpu as T
+    rng = np.random.default_rng(2024)
+    # learnable structure: class-dependent smooth patterns + noise (labels are predictable from the image)
+    yy, xx = np.meshgrid(np.linspace(0, 1, 64, dtype=np.float32), np.linspace(0, 1, 64, dtype=np.float32), indexing="ij")
+    def batch(n):
+        y = rng.integers(0, 10, size=n)
+        base = np.stack([np.stack([0.5 + 0.4 * np.sin(2 * np.pi * ((k % 5 + 1) * xx + (k // 5) * yy) + c) for c in range(3)]) for k in y])
+        x = np.clip(base + 0.05 * rng.standard_normal(base.shape), 0, 1).astype(np.float32)
+        return x, y.astype(np.int64)
+    train = [batch(64) for _ in range(4)]
+    xv, yv = batch(64)
+    alpha, lr = 35.0, 1e-3
+    m = _model()
+    eng = _engine(m, max_batch=64)
+    p = T.build(state=ae_state_np())
+    opt = T.make_adam(p, lr)
+    le, lp = [], []
+    for step in range(120):
+        x, y = train[step % 4]
+        eng.train_step(_cuda(x), _cuda(y), alpha, lr)
+        le.append(float(eng.loss_last[0]))
+        lp.append(T.train_step(p, opt, torch.from_numpy(x), torch.from_numpy(y), alpha))
+    le, lp = np.array(le), np.array(lp)
+    assert np.isfinite(le).all() and eng.gate_timeouts() == 0
+    for w in range(0, 120, 20):
+        a, b = le[w:w + 20].mean(), lp[w:w + 20].mean()
+        assert abs(a - b) <= 0.04 * b, (w, a, b)
+    assert le[-20:].mean() < 0.66 * le[:4].mean() and lp[-20:].mean() < 0.66 * lp[:4].mean()
+    # validation in eval mode
+    m.eval()
+    xh, lg, _ = eng.forward(_cuda(xv), train=False)
+    ve = alpha * float(((xh - _cuda(xv)) ** 2).mean()) + float(torch.nn.functional.cross_entropy(lg, _cuda(yv)))
+    with torch.no_grad():
+        xr, lr_, _ = T.forward(p, torch.from_numpy(xv), train=False)
+        vp = alpha * float(((xr - torch.from_numpy(xv)) ** 2).mean()) + float(torch.nn.functional.cross_entropy(lr_, torch.from_numpy(yv)))
+    assert abs(ve - vp) <= 0.05 * vp, (ve, vp)
