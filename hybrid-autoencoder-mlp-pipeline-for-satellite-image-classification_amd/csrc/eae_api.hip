@@ -674,7 +674,7 @@ void fp8_conv_args(eae_ctx* c, ConvArgs& a, int j, bool forward, bool p1) {
   a.wpack = (const bf16_t*)(c->pack + (p1 ? c->pk8_p1[j] : c->pk8_p2[j]));
   a.qs = forward ? c->q->qs_fwd[j] : c->q->qs_bwd[j];
   a.amax = forward ? c->q->amax_act[j] : c->q->amax_grad[j];
-  a.amax_mask = FP8_AMAX_SLOTS - 1;
+  a.amax_mask = FP8_AMAX_SLOTS - 1; a.amax_stride = FP8_AMAX_STRIDE;
 }
 
 // producer side of the folded forward finalize of BN layer l

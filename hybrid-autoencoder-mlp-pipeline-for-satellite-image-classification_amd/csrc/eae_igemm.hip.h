@@ -46,7 +46,8 @@ struct ConvArgs {
   // |staged value| (bf16 bits << 16, atomicMax) for the next step's scale (delayed scaling, eae_fp8.hip)
   const float* qs;
   unsigned* amax;
-  int amax_mask;          // amax is an array of amax_mask + 1 words (a power of two): workgroup t reports into word t & amax_mask
+  int amax_mask;          // amax is an array of amax_mask + 1 slots (a power of two): workgroup t reports into slot t & amax_mask
+  int amax_stride;        // words between two slots (the engine: 32 = one 128-byte line per slot; per-op calls: 0 slots -> unused)
 #ifdef EAE_STAMPS
   unsigned long long* dbg; // diagnostic build only: s_memtime stamps of workgroup `dbg_block`, wave 0
   int dbg_block;
@@ -661,7 +662,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
     for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o = __shfl_xor(wmax, sh); wmax = o > wmax ? o : wmax; }
     // agent-scope atomics on ONE word serialise at the memory side (~50 ns each: 4096 workgroups of a 256x256 batch made this kernel
     // 4x slower than its bf16 twin, profiles/r03_bench_c5fp8_kernel_stats.csv before the change); the engine hands in 64 words
-    if (lane == 0 && wmax != 0) atomicMax(a.amax + (tile_id & a.amax_mask), wmax << 16);
+    if (lane == 0 && wmax != 0) atomicMax(a.amax + (size_t)(tile_id & a.amax_mask) * a.amax_stride, wmax << 16);
   }
   EAE_STAMP(7);
   EAE_STAMP_WG(1);

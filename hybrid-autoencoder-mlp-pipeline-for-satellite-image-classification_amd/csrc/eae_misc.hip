@@ -286,7 +286,7 @@ __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc*
     }
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&q->amax_w[d.q_layer][(blockIdx.x * 4 + (threadIdx.x >> 6)) & (FP8_AMAX_SLOTS - 1)], __float_as_uint(mx));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&q->amax_w[d.q_layer][((blockIdx.x * 4 + (threadIdx.x >> 6)) & (FP8_AMAX_SLOTS - 1)) * FP8_AMAX_STRIDE], __float_as_uint(mx));
     return;
   }
   if ((d.mode == PACK_3x3_P1 || d.mode == PACK_3x3_P2) && !d.out_f32) {
@@ -416,13 +416,19 @@ __device__ __forceinline__ float fp8_scale_from(unsigned amax_bits, float maxv, 
   return exp2f(fminf(fmaxf(e, -60.f), 60.f));
 }
 __global__ EAE_NO_PK void fp8_scales_kernel(Fp8State* q) {
-  static_assert(FP8_AMAX_SLOTS == 64, "one word per lane");
+  static_assert(FP8_AMAX_SLOTS % 64 == 0, "whole rounds of one slot per lane");
   const int lane = threadIdx.x;
   unsigned ma[6], mg[6], mw[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    ma[i] = q->amax_act[i][lane]; mg[i] = q->amax_grad[i][lane]; mw[i] = q->amax_w[i][lane];
-    q->amax_act[i][lane] = 0; q->amax_grad[i][lane] = 0; q->amax_w[i][lane] = 0;
+    ma[i] = mg[i] = mw[i] = 0u;
+#pragma unroll
+    for (int s0 = 0; s0 < FP8_AMAX_SLOTS; s0 += 64) {
+      const int w_ = (s0 + lane) * FP8_AMAX_STRIDE;
+      const unsigned a_ = q->amax_act[i][w_], g_ = q->amax_grad[i][w_], x_ = q->amax_w[i][w_];
+      ma[i] = a_ > ma[i] ? a_ : ma[i]; mg[i] = g_ > mg[i] ? g_ : mg[i]; mw[i] = x_ > mw[i] ? x_ : mw[i];
+      q->amax_act[i][w_] = 0; q->amax_grad[i][w_] = 0; q->amax_w[i][w_] = 0;
+    }
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) {       // (non-negative float bits order like unsigned integers)
       const unsigned a = __shfl_xor(ma[i], sh), g = __shfl_xor(mg[i], sh), w = __shfl_xor(mw[i], sh);
