@@ -659,6 +659,16 @@ int ensure_packed(eae_ctx* c, hipStream_t st) {
   return 0;
 }
 
+// split-K of the latent projections: K-range per slice.  128 (32 slices) at the reference's 64x64 inputs; wider inputs keep the number
+// of slices at EAE_FC_SLICES (default 128): K / 128 = 512 slices at 256x256 wrote and re-read 67 MB of partials per projection, but the
+// kernel's K loop is not software-pipelined, so long ranges cost more than the partials save (ms per config-5 step with 512 / 128 / 64 /
+// 32 / 16 slices: 2.096 / 2.070 / 2.083 / 2.136 / 2.223)
+int fc_klen(const eae_ctx* c) {
+  static const int slices = getenv("EAE_FC_SLICES") ? atoi(getenv("EAE_FC_SLICES")) : 128;
+  long long klen = 128;
+  while (c->K / klen > slices && c->K % (klen * 2) == 0) klen *= 2;
+  return (int)klen;
+}
 SrcDesc src_raw(const bf16_t* p) { SrcDesc s; s.p0 = p; s.p1 = nullptr; s.coef = nullptr; return s; }
 SrcDesc src_bnrelu(const bf16_t* y, const float* coef) { SrcDesc s; s.p0 = y; s.p1 = nullptr; s.coef = coef; return s; }
 SrcDesc src_bnbwd(const bf16_t* g, const bf16_t* y, const float* coef) { SrcDesc s; s.p0 = g; s.p1 = y; s.coef = coef; return s; }
@@ -828,9 +838,9 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
   FcNtArgs f = FcNtArgs();
   f.a = src_bnrelu(c->y[3], c->coef_f[3]);
   f.w = (const bf16_t*)(c->pack + c->pk_we1);
-  f.M = B; f.N = c->Lp; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
+  f.M = B; f.N = c->Lp; f.K = (int)c->K; f.klen = fc_klen(c); f.part = c->fcpart;
   fold_consumer(c, f.fold, 3, (long long)B * c->Pn, train);
-  const int ksplit = (int)(c->K / 128);
+  const int ksplit = (int)(c->K / f.klen);
   RC(eae_launch_fc_nt(st, f, SRC_BNRELU, FCE_PARTIAL, ksplit));
   RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->Lp, c->lpad ? (const float*)(c->pack + c->pk_bep) : c->P + c->poff[17], nullptr,
                           nullptr, c->z));
@@ -1077,10 +1087,10 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     {
       FcNtArgs f = FcNtArgs();
       f.a = src_raw(c->gd0); f.w = (const bf16_t*)(c->pack + c->pk_wd2);
-      f.M = B; f.N = c->Lp; f.K = (int)c->K; f.klen = 128; f.part = c->fcpart;
+      f.M = B; f.N = c->Lp; f.K = (int)c->K; f.klen = fc_klen(c); f.part = c->fcpart;
       f.c = ConvArgs();
       take_sig(c, f.c);
-      const int ksplit = (int)(c->K / 128);
+      const int ksplit = (int)(c->K / f.klen);
       RC(eae_launch_fc_nt(st, f, SRC_RAW, FCE_PARTIAL, ksplit));
       if (c->sq_forked) RC(sq_commit(c, st));
       if (c->head_pending) { EAE_HIP(hipStreamWaitEvent(st, c->ev_head, 0)); c->head_pending = false; }
