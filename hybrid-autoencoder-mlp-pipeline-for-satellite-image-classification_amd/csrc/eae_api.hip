@@ -660,11 +660,10 @@ int ensure_packed(eae_ctx* c, hipStream_t st) {
 }
 
 // split-K of the latent projections: K-range per slice.  128 (32 slices) at the reference's 64x64 inputs; wider inputs keep the number
-// of slices at EAE_FC_SLICES (default 128): K / 128 = 512 slices at 256x256 wrote and re-read 67 MB of partials per projection, but the
-// kernel's K loop is not software-pipelined, so long ranges cost more than the partials save (ms per config-5 step with 512 / 128 / 64 /
-// 32 / 16 slices: 2.096 / 2.070 / 2.083 / 2.136 / 2.223)
+// of slices at EAE_FC_SLICES (default 64): K / 128 = 512 slices at 256x256 wrote and re-read 67 MB of partials per projection (ms per
+// config-5 step with 512 / 128 / 64 / 32 / 16 slices: 2.066 / 2.050 / 2.040 / 2.058 / 2.107, with the prefetching K loop of fc_nt_kernel)
 int fc_klen(const eae_ctx* c) {
-  static const int slices = getenv("EAE_FC_SLICES") ? atoi(getenv("EAE_FC_SLICES")) : 128;
+  static const int slices = getenv("EAE_FC_SLICES") ? atoi(getenv("EAE_FC_SLICES")) : 64;
   long long klen = 128;
   while (c->K / klen > slices && c->K % (klen * 2) == 0) klen *= 2;
   return (int)klen;
