@@ -55,6 +55,7 @@ _PROTOS = {
     "eae_ae_grad_step_begin": (C.c_int, [vp, vp, C.POINTER(EaeStepIO)]),
     "eae_ae_grad_step_end": (C.c_int, [vp, vp]),
     "eae_side_stream": (vp, [vp]),
+    "eae_debug_read": (C.c_longlong, [vp, C.c_int, C.c_int, vp, C.c_longlong]),
     "eae_dp_stream": (vp, [vp, C.c_int]),
     "eae_adam_step_scaled": (C.c_int, [vp, vp, C.c_float, C.c_float, C.c_float]),
     "eae_dp_unique_id": (C.c_int, [vp]),

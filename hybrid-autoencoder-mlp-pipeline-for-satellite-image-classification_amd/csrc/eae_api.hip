@@ -88,6 +88,9 @@ struct eae_ctx {
   // workspace
   void* ws = nullptr;
   bf16_t *y[4], *u[3], *d0, *gy[4], *gu[3], *gd0, *g4;
+  // dy = BatchNorm-backward-applied gradients, written by the backward-data kernels while they stage them (ConvArgs::dy_out) and
+  // read by the weight-gradient kernels: dyy[i] has the shape of gy[i] (i = 1..3), dyu[i] that of gu[i]
+  bf16_t *dyy[4], *dyu[3];
   float *z, *dz, *dzc, *coef_f[7], *coef_b[7], *stat, *wscratch, *fcpart, *msepart, *cepart, *headpart, *lossbuf;
   long long wscratch_floats, head_stride;
   uint8_t* pack = nullptr;
@@ -144,6 +147,11 @@ struct eae_ctx {
   unsigned* sigwords = nullptr;
   unsigned side_done_seq[1 + MAXX] = {};
   unsigned side_used = 0;          // bit k: side stream k received work since the last join
+  // Per layer: does the backward-data kernel store dy (ConvArgs::dy_out) for the weight gradient, which then runs BEHIND it on one
+  // plain tensor, or does the weight gradient transform g and y itself and run BESIDE the backward-data kernel?  bit i (1..3) =
+  // enc.conv(i+1), bit 4 + i (0..2) = dec.deconv(i+1).  EAE_DY_MASK overrides (diagnostic A/B).
+  unsigned dy_mask = 0;
+  bool skip_wgrad = false;         // EAE_SKIP_WGRAD=1 (diagnostic): the six 3x3 weight gradients are not launched (main chain alone)
   bool use_gates = true;           // device-side gates instead of event records on the caller's stream (EAE_FORK_EVENTS=1: events)
   unsigned long long gate_limit = 3000000000ULL;     // gate spin bound in 100 MHz ticks (30 s; EAE_GATE_TIMEOUT_MS, 0 = unbounded)
   float* last_loss = nullptr;      // the caller's loss_last buffer of the most recent step: poisoned with NaN when a gate has timed out
@@ -212,9 +220,12 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   // ---- carve one allocation
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  size_t o_y[4], o_u[3], o_gy[4], o_gu[3];
+  size_t o_y[4], o_u[3], o_gy[4], o_gu[3], o_dyy[4] = {0, 0, 0, 0}, o_dyu[3];
   for (int i = 0; i < 4; ++i) { o_y[i] = carve(Bm * c->act_elems(i + 1) * 2); o_gy[i] = carve(Bm * c->act_elems(i + 1) * 2); }
   for (int i = 0; i < 3; ++i) { o_u[i] = carve(Bm * c->act_elems(3 - i) * 2); o_gu[i] = carve(Bm * c->act_elems(3 - i) * 2); }
+  const unsigned dy_mask_env = (getenv("EAE_DY_MASK") ? (unsigned)strtoul(getenv("EAE_DY_MASK"), nullptr, 0) : 0u) & 0x3cu;
+  for (int i = 1; i < 4; ++i) o_dyy[i] = ((dy_mask_env >> i) & 1u) ? carve(Bm * c->act_elems(i + 1) * 2) : 0;
+  for (int i = 0; i < 3; ++i) o_dyu[i] = ((dy_mask_env >> (4 + i)) & 1u) ? carve(Bm * c->act_elems(3 - i) * 2) : 0;
   size_t o_d0 = carve(Bm * c->K * 2), o_gd0 = carve(Bm * c->K * 2), o_g4 = carve(Bm * (size_t)c->H * c->W * 4 * 2);
   size_t o_z = carve(Bm * c->Lp * 4), o_dz = carve(Bm * c->Lp * 4), o_dzc = carve(Bm * c->Lp * 4);
   size_t o_cf[7], o_cb[7];
@@ -308,7 +319,12 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   if (e != hipSuccess) { delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
   uint8_t* b = static_cast<uint8_t*>(c->ws);
   for (int i = 0; i < 4; ++i) { c->y[i] = (bf16_t*)(b + o_y[i]); c->gy[i] = (bf16_t*)(b + o_gy[i]); }
-  for (int i = 0; i < 3; ++i) { c->u[i] = (bf16_t*)(b + o_u[i]); c->gu[i] = (bf16_t*)(b + o_gu[i]); }
+  for (int i = 0; i < 3; ++i) {
+    c->u[i] = (bf16_t*)(b + o_u[i]); c->gu[i] = (bf16_t*)(b + o_gu[i]);
+    c->dyu[i] = ((dy_mask_env >> (4 + i)) & 1u) ? (bf16_t*)(b + o_dyu[i]) : nullptr;
+  }
+  c->dyy[0] = nullptr;
+  for (int i = 1; i < 4; ++i) c->dyy[i] = ((dy_mask_env >> i) & 1u) ? (bf16_t*)(b + o_dyy[i]) : nullptr;
   c->d0 = (bf16_t*)(b + o_d0); c->gd0 = (bf16_t*)(b + o_gd0); c->g4 = (bf16_t*)(b + o_g4);
   c->z = (float*)(b + o_z); c->dz = (float*)(b + o_dz); c->dzc = (float*)(b + o_dzc);
   if (c->lpad) {
@@ -349,6 +365,12 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   if (e == hipSuccess) e = hipMemset(c->acc_base, 0, c->acc_bytes);
   if (e == hipSuccess) e = hipMemset(c->sigwords, 0, 64);
   c->acc_clean = true; c->bwd_dirty = false;
+  // Default OFF (round 4, measured): with dy the weight-gradient kernels lose a third of their stand-alone time (31-35 -> 27-32 us),
+  // but they start one kernel later and the backward-data kernels -- the critical chain -- carry the extra stores: ms per step at
+  // B=512 with dy for no layer / conv3+conv4 / deconv1+deconv2 / all four: 0.4840 / 0.4833 / 0.4861 / 0.4933.  The 32 <-> 64-channel
+  // layers' backward-data kernels are built without the store (eae_igemm.hip.h: DY), so bits 1 and 6 are never honoured.
+  c->dy_mask = (getenv("EAE_DY_MASK") ? (unsigned)strtoul(getenv("EAE_DY_MASK"), nullptr, 0) : 0u) & 0x3cu;
+  c->skip_wgrad = getenv("EAE_SKIP_WGRAD") != nullptr;
   c->fold_fwd = getenv("EAE_NO_FOLD_FWD") == nullptr;
   c->fold_bwd = getenv("EAE_NO_FOLD_BWD") == nullptr;
   if (e != hipSuccess) { hipFree(c->ws); delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
@@ -1036,19 +1058,28 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     for (int i = 2; i >= 0; --i) {
       const int cs = dcin[i], cb = dcin[i] / 2;         // deconv weight [cs][cb][3][3]
       const int Hs = H >> (4 - i), Ws = W >> (4 - i);   // input (small) map of the deconv
-      sq_push(c, [=](hipStream_t s2, float* scr) {       // needs coef_b[4+i] (BN-backward finalize of this layer's output)
-        WgradArgs w = WgradArgs();
-        w.small = (i == 0) ? src_raw(c->d0) : src_bnrelu(c->u[i - 1], c->coef_f[3 + i]);
-        w.big = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
-        w.B = B; w.Hs = Hs; w.Ws = Ws;
-        fold_bwd_consumer(c, w.bfold, 4 + i, (long long)B * (Hs * 2) * (Ws * 2), false);
-        if (c->fp8) w.qs = c->q->qs_wg[3 + i];
-        return eae_launch_wgrad_s2(s2, w, cs, cb, i == 0 ? SRC_RAW : SRC_BNRELU, SRC_BNBWD, scr, c->wscratch_floats, c->G + c->poff[20 + 4 * i],
-                                   prof_hook_for(c, EAE_PROF_SITE(4 + i, 2)));
-      });
-      if (i == 0) sq_fork(c); else fork_if_every();
+      // dy mode: backward-data first -- while it stages dy = BatchNorm-backward(g, y) of this layer's output it also stores it
+      // (dy_out); the weight gradient queued behind it reads that one tensor and is released when the NEXT kernel of the chain
+      // starts.  Otherwise the weight gradient transforms g and y itself and is released together with the backward-data kernel.
+      const bool dym = (c->dy_mask >> (4 + i)) & 1u;
+      auto push_wgrad = [&]() {
+        if (c->skip_wgrad) return;
+        sq_push(c, [=](hipStream_t s2, float* scr) {
+          WgradArgs w = WgradArgs();
+          w.small = (i == 0) ? src_raw(c->d0) : src_bnrelu(c->u[i - 1], c->coef_f[3 + i]);
+          w.big = dym ? src_raw(c->dyu[i]) : src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
+          w.B = B; w.Hs = Hs; w.Ws = Ws;
+          if (!dym) fold_bwd_consumer(c, w.bfold, 4 + i, (long long)B * (Hs * 2) * (Ws * 2), false);
+          if (c->fp8) w.qs = c->q->qs_wg[3 + i];
+          return eae_launch_wgrad_s2(s2, w, cs, cb, i == 0 ? SRC_RAW : SRC_BNRELU, dym ? SRC_RAWG : SRC_BNBWD, scr, c->wscratch_floats,
+                                     c->G + c->poff[20 + 4 * i], prof_hook_for(c, EAE_PROF_SITE(4 + i, 2)));
+        });
+        if (i == 0) sq_fork(c); else fork_if_every();
+      };
+      if (!dym) push_wgrad();
       ConvArgs a = ConvArgs();
       a.src = src_bnbwd(c->gu[i], c->u[i], c->coef_b[4 + i]);
+      a.dy_out = dym ? c->dyu[i] : nullptr;
       a.wpack = (const bf16_t*)(c->pack + c->pk_p1[3 + i]);
       a.B = B; a.Hin = Hs * 2; a.Win = Ws * 2;
       fold_bwd_consumer(c, a.bfold, 4 + i, (long long)B * a.Hin * a.Win, true);
@@ -1071,6 +1102,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
         }
         if (c->sq_forked) RC(sq_commit(c, st));
       }
+      if (dym) push_wgrad();
     }
     // ---- dec.fc: weight/bias gradient (queued: needs gd0) and dz
     sq_push(c, [=](hipStream_t s2, float*) {
@@ -1136,19 +1168,25 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
   for (int i = 3; i >= 1; --i) {
     const int cs = ENC_C[i + 1], cb = ENC_C[i];       // conv weight [cs][cb][3][3]
     const int Hs = H >> (i + 1), Ws = W >> (i + 1);   // output (small) map of the conv
-    sq_push(c, [=](hipStream_t s2, float* scr) {         // needs coef_b[i]
-      WgradArgs w = WgradArgs();
-      w.small = src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
-      w.big = src_bnrelu(c->y[i - 1], c->coef_f[i - 1]);
-      w.B = B; w.Hs = Hs; w.Ws = Ws;
-      fold_bwd_consumer(c, w.bfold, i, (long long)B * Hs * Ws, false);
-      if (c->fp8) w.qs = c->q->qs_wg[i - 1];
-      return eae_launch_wgrad_s2(s2, w, cs, cb, SRC_BNBWD, SRC_BNRELU, scr, c->wscratch_floats, c->G + c->poff[4 * i],
-                                 prof_hook_for(c, EAE_PROF_SITE(i, 2)));
-    });
-    if (i != 3) sq_fork(c); else fork_if_every();
+    const bool dym = (c->dy_mask >> i) & 1u;         // (see the transposed layers above)
+    auto push_wgrad = [&]() {
+      if (c->skip_wgrad) return;
+      sq_push(c, [=](hipStream_t s2, float* scr) {
+        WgradArgs w = WgradArgs();
+        w.small = dym ? src_raw(c->dyy[i]) : src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
+        w.big = src_bnrelu(c->y[i - 1], c->coef_f[i - 1]);
+        w.B = B; w.Hs = Hs; w.Ws = Ws;
+        if (!dym) fold_bwd_consumer(c, w.bfold, i, (long long)B * Hs * Ws, false);
+        if (c->fp8) w.qs = c->q->qs_wg[i - 1];
+        return eae_launch_wgrad_s2(s2, w, cs, cb, dym ? SRC_RAWG : SRC_BNBWD, SRC_BNRELU, scr, c->wscratch_floats, c->G + c->poff[4 * i],
+                                   prof_hook_for(c, EAE_PROF_SITE(i, 2)));
+      });
+      sq_fork(c);              // released by the next kernel of the chain (dy mode, conv2: by conv1's weight gradient)
+    };
+    if (!dym) push_wgrad();
     ConvArgs a = ConvArgs();
     a.src = src_bnbwd(c->gy[i], c->y[i], c->coef_b[i]);
+    a.dy_out = dym ? c->dyy[i] : nullptr;
     a.wpack = (const bf16_t*)(c->pack + c->pk_p2[i - 1]);
     a.out = c->gy[i - 1]; a.stat_part = c->stat; a.yprev = c->y[i - 1]; a.prev_coef = c->coef_f[i - 1];
     a.B = B; a.Hin = Hs; a.Win = Ws;
@@ -1162,7 +1200,9 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     }
     if (c->sq_forked) RC(sq_commit(c, st));
     RC(bn_bwd_fin(c, st, i - 1, eae_conv_s2_ntiles(1, B, Hs, Ws, cs), (long long)B * (Hs * 2) * (Ws * 2)));
-    if (i == 2 && part == 0 && c->dp_stream[1]) {     // enc.fc, conv4 and conv3 weight gradients have been enqueued
+    if (dym) push_wgrad();
+    if (i == 2 && part == 0 && c->dp_stream[1]) {     // enc.fc, conv4 and conv3 weight gradients: enqueued by the commit below
+      RC(sq_commit(c, st));
       RC(fold_side2(c));
       EAE_HIP(hipEventRecord(c->ev_part[1], c->side));
       EAE_HIP(hipStreamWaitEvent(c->dp_stream[1], c->ev_part[1], 0));
@@ -1172,8 +1212,12 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
   //      latency in the tail of the step) while the side streams drain
   BnBwdFold bf0;
   fold_bwd_consumer(c, bf0, 0, (long long)B * (H / 2) * (W / 2), true);
-  RC(eae_launch_edge_wgrad(st, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, c->wscratch_main,
-                           2048LL * 864, c->G + c->poff[0], prof_hook_for(c, EAE_PROF_CONV1_WGRAD), &bf0));
+  {
+    ConvArgs sg = ConvArgs();                          // carries the progress value that releases conv2's weight gradient
+    take_sig(c, sg);
+    RC(eae_launch_edge_wgrad(st, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, c->wscratch_main,
+                             2048LL * 864, c->G + c->poff[0], prof_hook_for(c, EAE_PROF_CONV1_WGRAD), &bf0, sg.sig, sg.sig_val));
+  }
   RC(join_side(c, st));
   if (c->fp8) RC(eae_launch_fp8_scales(st, c->q));      // every reader of this step's scales has finished: derive the next step's
   // Biases in front of a BatchNorm have an identically zero gradient (the reference computes ~1e-9 rounding noise);
@@ -1290,6 +1334,21 @@ extern "C" int eae_ae_grad_step_end(eae_ctx* c, void* stream) {
   return rc;
 }
 extern "C" void* eae_side_stream(eae_ctx* c) { return c ? (void*)c->side : nullptr; }
+// Test / diagnostic access to the engine's workspace tensors of the most recent step (device synchronised first; bf16 NHWC, sized
+// for the context's max_batch): kind 0 = y[idx] (idx 0..3), 1 = gy[idx], 2 = u[idx] (0..2), 3 = gu[idx], 4 = dyy[idx] (1..3), 5 = dyu[idx].
+// Copies up to `bytes` to `host_dst`, returns the number of bytes copied or a negative status.
+extern "C" long long eae_debug_read(eae_ctx* c, int kind, int idx, void* host_dst, long long bytes) {
+  if (!c || !host_dst) return eae_set_error(EAE_ERR_ARG, "debug_read: null argument");
+  const bool enc = kind == 0 || kind == 1 || kind == 4;
+  if (kind < 0 || kind > 5 || idx < 0 || idx > (enc ? 3 : 2) || (kind == 4 && idx == 0)) return eae_set_error(EAE_ERR_ARG, "debug_read: no such tensor");
+  const bf16_t* p = kind == 0 ? c->y[idx] : kind == 1 ? c->gy[idx] : kind == 2 ? c->u[idx] : kind == 3 ? c->gu[idx] : kind == 4 ? c->dyy[idx] : c->dyu[idx];
+  if (!p) return eae_set_error(EAE_ERR_STATE, "debug_read: this context keeps no dy tensor for that layer (EAE_DY_MASK)");
+  const long long have = (long long)c->Bm * c->act_elems(enc ? idx + 1 : 3 - idx) * 2;
+  if (bytes > have) bytes = have;
+  EAE_HIP(hipDeviceSynchronize());
+  EAE_HIP(hipMemcpy(host_dst, p, (size_t)bytes, hipMemcpyDeviceToHost));
+  return bytes;
+}
 extern "C" void* eae_dp_stream(eae_ctx* c, int which) {
   if (!c || !c->use_side || which < 0 || which > 1) return nullptr;
   if (!c->dp_stream[which]) {

@@ -13,7 +13,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 enum { SRC_RAW = 0,      // bf16 tensor as stored
        SRC_BNRELU = 1,   // max(0, s[c]*y + t[c])            (BatchNorm apply + ReLU fused into the consumer's load)
        SRC_BNBWD = 2,    // A[c]*g + B[c]*y + C[c]           (BatchNorm backward apply fused into the consumer's load)
-       SRC_F32 = 3 };    // fp32 tensor, converted to bf16 on load
+       SRC_F32 = 3,      // fp32 tensor, converted to bf16 on load
+       SRC_RAWG = 4 };   // bf16 GRADIENT tensor as stored (the BatchNorm-backward-applied dy a backward-data kernel wrote while it staged
+                         // its patch, ConvArgs::dy_out): loads like SRC_RAW; the fp8 variants convert it to e5m2 like SRC_BNBWD
 
 // epilogues of the conv-like kernels
 enum { EPI_FWD = 0,      // + bias, store raw bf16, per-channel sum / sum-of-squares partials (BatchNorm batch statistics)
@@ -96,10 +98,13 @@ template <int MODE> struct RawPiece { u32x4 v0, v1; };
 
 // byte_off = byte offset of the piece inside the tensor, or OOB_OFF for a piece outside the image
 // AUX = cache-policy bits of the load (0 = default, 2 = nt: streamed once, do not keep in L2)
+// `soff` = wave-uniform byte offset added by the hardware AFTER the range check of byte_off (an out-of-range byte_off stays out of
+// range whatever soff is): a compile-time soff folds into the instruction's immediate, so stepping through channel chunks costs no
+// vector instruction and no select on the validity of the piece
 template <int MODE, int AUX = 0>
-__device__ __forceinline__ void load_piece_b(const SrcRsrc& rs, uint32_t byte_off, RawPiece<MODE>& r) {
-  r.v0 = __builtin_amdgcn_raw_buffer_load_b128(rs.r0, byte_off, 0, AUX);
-  if (MODE == SRC_BNBWD) r.v1 = __builtin_amdgcn_raw_buffer_load_b128(rs.r1, byte_off, 0, AUX);
+__device__ __forceinline__ void load_piece_b(const SrcRsrc& rs, uint32_t byte_off, RawPiece<MODE>& r, int soff = 0) {
+  r.v0 = __builtin_amdgcn_raw_buffer_load_b128(rs.r0, byte_off, soff, AUX);
+  if (MODE == SRC_BNBWD) r.v1 = __builtin_amdgcn_raw_buffer_load_b128(rs.r1, byte_off, soff, AUX);
 }
 
 // compatibility form (element offset + validity flag)
@@ -115,7 +120,7 @@ __device__ __forceinline__ void load_piece(const SrcDesc& s, size_t off, bool va
 template <int MODE>
 __device__ __forceinline__ uint4 transform_piece(const RawPiece<MODE>& r, bool valid, const ChanCoef<MODE>& cc) {
   uint4 o;
-  if (MODE == SRC_RAW) { o.x = r.v0[0]; o.y = r.v0[1]; o.z = r.v0[2]; o.w = r.v0[3]; return o; }
+  if (MODE == SRC_RAW || MODE == SRC_RAWG) { o.x = r.v0[0]; o.y = r.v0[1]; o.z = r.v0[2]; o.w = r.v0[3]; return o; }
   uint32_t w[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {

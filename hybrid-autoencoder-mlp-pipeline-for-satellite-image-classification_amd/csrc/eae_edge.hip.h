@@ -232,10 +232,13 @@ struct EdgeWgradArgs {
   float* part;            // [nblocks][32*27]
   int tiles_per_block, ntiles;
   BnBwdFold bfold;        // SRC_BNBWD side: coefficient table from the layer's backward accumulators (eae_common.hip.h)
+  unsigned* sig;          // progress word of the caller's stream, published when the kernel starts (ConvArgs::sig); nullptr: none
+  unsigned sig_val;
 };
 
 template <int SRC3, int SMODE>
 __global__ __launch_bounds__(256) void edge_wgrad_kernel(EdgeWgradArgs a) {
+  eae_signal(a.sig, a.sig_val);
   __shared__ __attribute__((aligned(16))) bf16_t p3[E_PATCH];
   // the two operand tiles; the cross-wave reduction image of the epilogue (16 KB) reuses them (41.9 -> 26 KB of LDS per block:
   // 6 instead of 3 blocks per CU)

@@ -27,10 +27,12 @@ int eae_edge_tiles(int B, int H, int W) { return B * (H / 2 / E_TH) * (W / 2 / E
 
 // dw [32][3][3][3] = reduce over blocks of the per-block partials. scratch must hold nblocks*864 floats.
 int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B, int H, int W, const SrcDesc& side, int smode,
-                          float* scratch, long long scratch_floats, float* dw, const EaeProfHook* hook, const BnBwdFold* bfold) {
+                          float* scratch, long long scratch_floats, float* dw, const EaeProfHook* hook, const BnBwdFold* bfold,
+                          unsigned* sig, unsigned sig_val) {
   if (int rc = check_edge_shape(B, H, W)) return rc;
   EdgeWgradArgs a;
   a.bfold = bfold ? *bfold : BnBwdFold();
+  a.sig = sig; a.sig_val = sig_val;
   a.src3 = src3; a.B = B; a.H = H; a.W = W; a.side = side; a.part = scratch;
   a.ntiles = eae_edge_tiles(B, H, W);
   static const int cap = getenv("EAE_EDGE_WGRAD_BLOCKS") ? atoi(getenv("EAE_EDGE_WGRAD_BLOCKS")) : 1024;   // 4 blocks per CU fit: one round of workgroups (0.510-0.514 vs 0.514-0.517 ms per step with 512)

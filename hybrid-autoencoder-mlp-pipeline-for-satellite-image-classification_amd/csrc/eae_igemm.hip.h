@@ -48,6 +48,10 @@ struct ConvArgs {
   unsigned* amax;
   int amax_mask;          // amax is an array of amax_mask + 1 slots (a power of two): workgroup t reports into slot t & amax_mask
   int amax_stride;        // words between two slots (the engine: 32 = one 128-byte line per slot; per-op calls: 0 slots -> unused)
+  // SRC_BNBWD only: the BatchNorm-backward-applied gradient dy = A*g + B*y + C, exactly as staged (bf16, the source tensor's NHWC
+  // layout), is ALSO stored here by channel block 0 of every tile, so that the layer's weight-gradient kernel reads ONE plain
+  // tensor instead of transforming g and y again (SRC_RAWG, eae_wgrad.hip.h).  nullptr: off
+  bf16_t* dy_out;
 #ifdef EAE_STAMPS
   unsigned long long* dbg; // diagnostic build only: s_memtime stamps of workgroup `dbg_block`, wave 0
   int dbg_block;
@@ -391,6 +395,15 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   const uint8_t* wrow8 = reinterpret_cast<const uint8_t*>(a.wpack) + (size_t)(n0 + wn * 16 + (lane & 15)) * 9 * CIN + kgl * 8;
   SrcRsrc rs;
   rs.init<SRC>(a.src);
+  // The 32 <-> 64-channel instances run at 3-4 workgroups per CU on 128-168 registers with 72 of them holding raw pieces: keeping the
+  // piece offsets alive until the staging loop cost them 100-290 bytes of scratch (dec.deconv3's backward-data: 35 -> 53 us in the
+  // step).  They are built without the store; the engine never asks them for dy (eae_api.hip: dy_mask).
+  constexpr bool DY = SRC == SRC_BNBWD && CIN * COUT > 2048;
+  const bool wr_dy = DY && a.dy_out != nullptr && nblk == 0;
+  // (a workgroup that does not store dy -- no dy_out, or not channel block 0 -- gets a descriptor of ZERO bytes: its stores are all
+  //  out of range and dropped by the hardware, so the staging loop needs no branch around them; a branch per piece cut the loop into
+  //  basic blocks and cost the 128-register instances scratch)
+  __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(DY ? a.dy_out : (bf16_t*)nullptr, 0, wr_dy ? 0x7fffff00 : 0, 0x00020000);
 
   // ---- patch pieces of this thread: piece q = tid + 256*i covers patch pixel q/4, channels kgs*8.. of the current
   //      K-chunk; consecutive i advance the pixel by 64 -> (img, row, col) are updated incrementally.  Byte offsets are
@@ -430,7 +443,7 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
     if (o == 0 && with_coef) cc.load(coefp, CIN, chunk * 32 + kgs * 8);
 #pragma unroll
     for (int i = 0; i < NPA; ++i)
-      if (i % G::NOFF == o) load_piece_b<SRC>(rs, val[i] ? boff[i] + chunk * 64 : OOB_OFF, raw[i]);
+      if (i % G::NOFF == o) load_piece_b<SRC>(rs, boff[i], raw[i], chunk * 64);      // (boff is OOB_OFF for a piece outside the image)
   };
   auto issue = [&](int chunk, bool with_coef) {
 #pragma unroll
@@ -483,6 +496,15 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
         const uint4 o = transform_piece<SRC>(raw[i], val[i], cc);
         if (Q) amax_run = amax_pk(amax_run, o);
         *reinterpret_cast<uint4*>(patch + loff[i]) = o;
+        // (Halo pieces are stored too: every workgroup that stages an element computes the same bits from the
+        //  same g, y and table, so the duplicate stores -- 10-25 % of a map -- are harmless, and the store reuses the load's offset:
+        //  a mask of owned pieces cost the 128-register instances 100-280 bytes of scratch)
+        if (DY)
+          // (the chunk offset goes into the VECTOR offset, never into soffset: for a 16-byte store whose soffset is an SGPR -- 128 and
+          //  192 are no inline constants -- hipcc (ROCm 7.2) omits the wait state between the store and a following VALU write of its
+          //  data registers, and on gfx950 the third dword of sporadic pieces of chunks 2 and 3 then came out as the NEXT piece's
+          //  intermediate: tools/debug_det.py found the stored dy differing from run to run in exactly those dwords)
+          __builtin_amdgcn_raw_buffer_store_b128((u32x4){o.x, o.y, o.z, o.w}, rs_dy, boff[i] + chunk * 64, 0, 0);
       }
     }
     EAE_STAMP(8 + chunk * 4 + 1);

@@ -59,20 +59,28 @@ template <int NPA, int SMODE, int BMODE>
 struct WgRaw {
   RawPiece<BMODE> b[NPA];
   RawPiece<SMODE> s[2];
-  bool bval[NPA], sval[2];
+  uint32_t vm;            // bit i: patch piece i is inside the image; bit 16 + i: S piece i is inside the batch
 };
 
-// Q = 1: both fragment operands converted in registers to fp8 right before the MFMA (e5m2 for the SRC_BNBWD gradient operand, e4m3
-// for the activation operand), accumulators rescaled in the epilogue (see igemm_body, eae_igemm.hip.h)
+#ifdef EAE_WG_EXP          // ablation builds: -DEAE_WG_EXP=<mask>, 1 = producers skip the stage, 2 = skip the re-issue, 4 = consumers skip the MFMAs
+#define WG_EXP(bit) (EAE_WG_EXP & (bit))
+#else
+#define WG_EXP(bit) 0
+#endif
+
+// Q = 1: both fragment operands converted in registers to fp8 right before the MFMA (e5m2 for the gradient operand -- SRC_BNBWD or
+// SRC_RAWG --, e4m3 for the activation operand), accumulators rescaled in the epilogue (see igemm_body, eae_igemm.hip.h)
 template <int CS, int CB, int TW, int TH, int NI, int SMODE, int BMODE, int Q>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   static_assert(NI * TH * TW == 128, "tile must hold 128 positions");
-  constexpr bool SG = (SMODE == SRC_BNBWD), BG = (BMODE == SRC_BNBWD);
+  static_assert(NI <= 8, "image index of a piece is kept in 4 bits");
+  constexpr bool SG = (SMODE == SRC_BNBWD || SMODE == SRC_RAWG), BG = (BMODE == SRC_BNBWD || BMODE == SRC_RAWG);
   if (Q) fp8_saturate_mode();
   const float q_s = Q ? a.qs[0] : 1.f, q_b = Q ? a.qs[1] : 1.f, q_out = Q ? a.qs[2] : 1.f;
   static_assert(CS % 64 == 0 && CB % 32 == 0, "shape");
   using G = WgGeo<TW, TH, NI>;
   constexpr int PH = G::PH, PW = G::PW, NPIX = G::NPIX, NPA = G::NPA;
+  static_assert(NPA <= 6, "piece masks: 6 patch pieces + 2 S pieces per producer thread");
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);      // 0..11, wave-uniform by construction
@@ -94,8 +102,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     else { oblk = bid % NBLK; slice = bid / NBLK; }
   }
   // a slice whose blocks are split over two XCDs: adjacent block ids share the channel block of the operand with MORE bytes per tile
-  // (the SRC_BNBWD one: g and y), so that each XCD fetches half of it and all of the lighter one (dec.deconv1: 2.05x -> ~1.4x)
-  const int cs0 = (BG ? oblk % (CS / 64) : oblk / (CB / 32)) * 64, cb0 = (BG ? oblk / (CS / 64) : oblk % (CB / 32)) * 32;
+  // (two source tensors: g and y), so that each XCD fetches half of it and all of the lighter one (dec.deconv1: 2.05x -> ~1.4x)
+  constexpr bool BHEAVY = (BMODE == SRC_BNBWD);
+  const int cs0 = (BHEAVY ? oblk % (CS / 64) : oblk / (CB / 32)) * 64, cb0 = (BHEAVY ? oblk / (CS / 64) : oblk % (CB / 32)) * 32;
   const int t_first = slice * a.tiles_per_block;
   int t_end = t_first + a.tiles_per_block;
   if (t_end > a.ntiles) t_end = a.ntiles;
@@ -123,36 +132,55 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     SrcRsrc rsb, rss;
     rsb.init<BMODE>(a.big);
     rss.init<SMODE>(a.small);
+    // Piece -> (image, row, column) is a property of the THREAD, not of the tile: byte offsets relative to the tile's first pixel and
+    // the "top halo row / left halo column / beyond the patch" flags are worked out once; per tile a piece costs an add, a bit test
+    // and a select.  (Round 3 redid the divisions for every piece of every tile: ~170 of the 414 vector instructions a producer wave
+    // spent per tile, on SIMDs it shares with the matrix waves -- by the ablation builds the producers alone needed 1.6 us per tile.)
+    uint32_t relb[NPA], rels[2];
+    uint32_t m_in = 0, m_top = 0, m_left = 0, imgpk = 0;
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const int pix = (tid + i * WG_PRODUCERS) >> 2;
+      const int img = pix / (PH * PW), rem = pix % (PH * PW);
+      const int pr = rem / PW, pc = rem % PW;
+      relb[i] = (uint32_t)(((img * Hb + pr) * Wb + pc) * CB + kgs4 * 8) * 2u;
+      if (pix < NPIX) m_in |= 1u << i;
+      if (pr == 0) m_top |= 1u << i;
+      if (pc == 0) m_left |= 1u << i;
+      imgpk |= (uint32_t)(img & 15) << (4 * i);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = (tid + i * WG_PRODUCERS) >> 3;
+      const int img = m / (TH * TW), ty = (m / TW) % TH, tx = m % TW;
+      rels[i] = (uint32_t)(((img * a.Hs + ty) * a.Ws + tx) * CS + kgs8 * 8) * 2u;
+      imgpk |= (uint32_t)img << (24 + 4 * i);
+    }
     using Raw = WgRaw<NPA, SMODE, BMODE>;
-    auto issue = [&](Raw& r, int t) __attribute__((always_inline)) {        // request the raw pieces of tile t
-      // the piece -> (image, row, column) arithmetic is redone per call on an opaque copy of the thread index: hoisted out of
-      // the tile loop it costs ~20 registers per lane, which pushes prefetched pieces into scratch (and a scratch reload behind
-      // the prefetch would wait for it: vector-memory results return in issue order)
-      int tq = tid;
-      asm volatile("" : "+v"(tq));
+    // request the raw pieces of tile t (live = false: a step past the end of the slice, every piece out of range -- the hardware
+    // returns zeros without a memory access)
+    auto issue = [&](Raw& r, int t, bool live) __attribute__((always_inline)) {
       const int txb = t % tiles_x; t /= tiles_x;
       const int tyb = t % tiles_y; t /= tiles_y;
       const int img0 = t * NI;
-      const int iy0 = 2 * tyb * TH - 1, ix0 = 2 * txb * TW - 1;
+      const int nleft = live ? a.B - img0 : 0;          // images of this tile that exist
+      // (wrapping arithmetic: the halo row / column of the first tile puts the base one row and one pixel in front of the tensor)
+      const uint32_t base_b = (uint32_t)(((img0 * Hb + 2 * tyb * TH - 1) * Wb + 2 * txb * TW - 1) * CB + cb0) * 2u;
+      const uint32_t base_s = (uint32_t)(((img0 * a.Hs + tyb * TH) * a.Ws + txb * TW) * CS + cs0) * 2u;
+      uint32_t vm = m_in | (3u << 16);
+      if (tyb == 0) vm &= ~m_top;
+      if (txb == 0) vm &= ~m_left;
+      if (nleft < NI) {                                  // wave-uniform and rare: the last tile of a batch that is no multiple of NI, dead steps
 #pragma unroll
-      for (int i = 0; i < NPA; ++i) {         // big-map patch (32 channels cb0..cb0+31)
-        const int pix = (tq + i * WG_PRODUCERS) >> 2;
-        const int img = pix / (PH * PW), rem = pix % (PH * PW);
-        const int pr = rem / PW, pc = rem % PW;
-        const int iy = iy0 + pr, ix = ix0 + pc, nn = img0 + img;
-        r.bval[i] = (pix < NPIX) && (nn < a.B) && (iy >= 0) && (iy < Hb) && (ix >= 0) && (ix < Wb);
-        const uint32_t off = ((uint32_t)((nn * Hb + iy) * Wb + ix) * CB + cb0 + kgs4 * 8) * 2u;
-        load_piece_b<BMODE>(rsb, r.bval[i] ? off : OOB_OFF, r.b[i]);
-      }
+        for (int i = 0; i < NPA; ++i) if ((int)((imgpk >> (4 * i)) & 15u) >= nleft) vm &= ~(1u << i);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {           // small-map tile [128 positions][64 channels cs0..]
-        const int m = (tq + i * WG_PRODUCERS) >> 3;
-        const int img = m / (TH * TW), ty = (m / TW) % TH, tx = m % TW;
-        const int nn = img0 + img;
-        r.sval[i] = nn < a.B;
-        const uint32_t off = ((uint32_t)((nn * a.Hs + tyb * TH + ty) * a.Ws + txb * TW + tx) * CS + cs0 + kgs8 * 8) * 2u;
-        load_piece_b<SMODE>(rss, r.sval[i] ? off : OOB_OFF, r.s[i]);
+        for (int i = 0; i < 2; ++i) if ((int)((imgpk >> (24 + 4 * i)) & 15u) >= nleft) vm &= ~(1u << (16 + i));
       }
+      r.vm = vm;
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) load_piece_b<BMODE>(rsb, ((vm >> i) & 1u) ? base_b + relb[i] : OOB_OFF, r.b[i]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) load_piece_b<SMODE>(rss, ((vm >> (16 + i)) & 1u) ? base_s + rels[i] : OOB_OFF, r.s[i]);
     };
     auto stage = [&](const Raw& r, bf16_t* buf) __attribute__((always_inline)) {   // load transforms, once per element, into a tile buffer
       bf16_t* patch = buf;
@@ -161,37 +189,37 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
       for (int i = 0; i < NPA; ++i) {
         const int qq = tid + i * WG_PRODUCERS;
         if (qq < NPIX * 4)
-          *reinterpret_cast<uint4*>(patch + (qq >> 2) * PIX_STRIDE + kgs4 * 8) = transform_piece<BMODE>(r.b[i], r.bval[i], ccb);
+          *reinterpret_cast<uint4*>(patch + (qq >> 2) * PIX_STRIDE + kgs4 * 8) = transform_piece<BMODE>(r.b[i], (r.vm >> i) & 1u, ccb);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int qq = tid + i * WG_PRODUCERS;
-        *reinterpret_cast<uint4*>(sl + (qq >> 3) * S_STRIDE + kgs8 * 8) = transform_piece<SMODE>(r.s[i], r.sval[i], ccs);
+        *reinterpret_cast<uint4*>(sl + (qq >> 3) * S_STRIDE + kgs8 * 8) = transform_piece<SMODE>(r.s[i], (r.vm >> (16 + i)) & 1u, ccs);
       }
     };
+    // EVERY step issues and stages, past the end of the slice with out-of-range offsets: with a fixed number of loads per step
+    // hipcc's s_waitcnt bookkeeping sees the same two register sets in flight on every path into the loop and waits
+    // vmcnt(loads of one tile) before a stage.  With the issues under `if (t + 3 < n)` (round 3) it merged the paths pessimistically
+    // and drained vmcnt(0) in every stage: one tile in flight, not two (tools/waitcnt_audit.py lists such loops).
     Raw ra, rb;
-    if (n > 0) {
-      issue(ra, t_first);
-      if (n > 1) issue(rb, t_first + 1);
-    }
+    issue(ra, t_first, n > 0);
+    issue(rb, t_first + 1, n > 1);
     if (folded_b) {
       __syncthreads(); __syncthreads();               // the consumers' coefficient-table barriers
       if (BMODE == SRC_BNBWD) ccb.load(coef_tab, CB, cb0 + kgs4 * 8);
       if (SMODE == SRC_BNBWD) ccs.load(coef_tab, CS, cs0 + kgs8 * 8);
     }
-    if (n > 0) {
-      stage(ra, buf0);
-      if (n > 2) issue(ra, t_first + 2);
-    }
+    stage(ra, buf0);
+    issue(ra, t_first + 2, n > 2);
     __syncthreads();                                  // tile 0 staged
     // step t (consumers multiply tile t): stage tile t+1 into the idle buffer, then re-issue its register set for tile t+3
     for (int t = 0; t < n; t += 2) {
-      if (t + 1 < n) { stage(rb, buf1); if (t + 3 < n) issue(rb, t_first + t + 3); }
+      if (!WG_EXP(1)) stage(rb, buf1);
+      if (!WG_EXP(2)) issue(rb, t_first + t + 3, t + 3 < n);
       __syncthreads();
-      if (t + 1 < n) {
-        if (t + 2 < n) { stage(ra, buf0); if (t + 4 < n) issue(ra, t_first + t + 4); }
-        __syncthreads();
-      }
+      if (!WG_EXP(1)) stage(ra, buf0);
+      if (!WG_EXP(2)) issue(ra, t_first + t + 4, t + 4 < n);
+      __syncthreads();
     }
     __syncthreads();                                  // consumers have written the epilogue image
   } else {
@@ -213,47 +241,56 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     const int ml = 8 * g + q;
     const int s_lo = ml * S_STRIDE + it0 * 16 + 4 * p, s_hi = s_lo + 4 * S_STRIDE;
     const int p_lo = pix_of(ml) * PIX_STRIDE + jt * 16 + 4 * p, p_hi = pix_of(ml + 4) * PIX_STRIDE + jt * 16 + 4 * p;
-    auto mfma_tile = [&](const bf16_t* buf) __attribute__((always_inline)) {   // 4 K-steps of 32 positions
+    // One tile = 36 steps (4 K-steps of 32 positions x 9 taps), each one patch fragment feeding two MFMAs.  The fragment of step
+    // s + LA is requested before the MFMAs of step s, and the order is pinned: left alone hipcc issued the reads of four steps, waited for
+    // the first and multiplied -- one exposed LDS round trip per eight MFMAs (round-3 ISA; the consumers alone needed 1760 cycles per
+    // tile for 1152 cycles of matrix issue).
+    auto mfma_tile = [&](const bf16_t* buf) __attribute__((always_inline)) {
       const bf16_t* patch = buf;
       const bf16_t* sl = buf + NPIX * PIX_STRIDE;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        constexpr int dummy = 0; (void)dummy;
+      constexpr int LA = 3;
+      auto rd_b = [&](int s) __attribute__((always_inline)) {
+        const int ks = s / 9, tap = s % 9;
         const int pk = ((ks * 32) / (TH * TW) * PH + 2 * (((ks * 32) / TW) % TH)) * PW + 2 * ((ks * 32) % TW);   // pix_of(32*ks), compile time
-        bf16x8 sa[2];
-        long sq[2] = {0, 0};
+        const int toff = (tap / 3) * PW + (tap % 3);
+        return tr_frag(patch + p_lo + (pk + toff) * PIX_STRIDE, patch + p_hi + (pk + toff) * PIX_STRIDE);
+      };
+      auto rd_s = [&](int ks, int ii) __attribute__((always_inline)) {
+        return tr_frag(sl + s_lo + ks * 32 * S_STRIDE + ii * 16, sl + s_hi + ks * 32 * S_STRIDE + ii * 16);
+      };
+      bf16x8 sa[2][2], bb[LA + 1];
+      long sq[2] = {0, 0};
+      sa[0][0] = rd_s(0, 0); sa[0][1] = rd_s(0, 1);
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          sa[ii] = tr_frag(sl + s_lo + ks * 32 * S_STRIDE + ii * 16, sl + s_hi + ks * 32 * S_STRIDE + ii * 16);
-          if (Q) sq[ii] = cvt8<SG>(sa[ii], q_s);
+      for (int s = 0; s < LA; ++s) bb[s] = rd_b(s);
+#pragma unroll
+      for (int s = 0; s < 36; ++s) {
+        const int ks = s / 9, tap = s % 9;
+        if (s + LA < 36) bb[(s + LA) % (LA + 1)] = rd_b(s + LA);
+        if (tap == 5 && ks < 3) { sa[(ks + 1) & 1][0] = rd_s(ks + 1, 0); sa[(ks + 1) & 1][1] = rd_s(ks + 1, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (Q) {
+          if (tap == 0) { sq[0] = cvt8<SG>(sa[ks & 1][0], q_s); sq[1] = cvt8<SG>(sa[ks & 1][1], q_s); }
+          const long bq = cvt8<BG>(bb[s % (LA + 1)], q_b);
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+            acc[tap][ii] = SG ? (BG ? __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(sq[ii], bq, acc[tap][ii], 0, 0, 0)
+                                    : __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(sq[ii], bq, acc[tap][ii], 0, 0, 0))
+                              : (BG ? __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(sq[ii], bq, acc[tap][ii], 0, 0, 0)
+                                    : __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(sq[ii], bq, acc[tap][ii], 0, 0, 0));
+        } else {
+          acc[tap][0] = mfma16(sa[ks & 1][0], bb[s % (LA + 1)], acc[tap][0]);
+          acc[tap][1] = mfma16(sa[ks & 1][1], bb[s % (LA + 1)], acc[tap][1]);
         }
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int toff = (tap / 3) * PW + (tap % 3);
-          bf16x8 bb = tr_frag(patch + p_lo + (pk + toff) * PIX_STRIDE, patch + p_hi + (pk + toff) * PIX_STRIDE);
-          if (Q) {
-            const long bq = cvt8<BG>(bb, q_b);
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-              acc[tap][ii] = SG ? (BG ? __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(sq[ii], bq, acc[tap][ii], 0, 0, 0)
-                                      : __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(sq[ii], bq, acc[tap][ii], 0, 0, 0))
-                                : (BG ? __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(sq[ii], bq, acc[tap][ii], 0, 0, 0)
-                                      : __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(sq[ii], bq, acc[tap][ii], 0, 0, 0));
-          } else {
-            acc[tap][0] = mfma16(sa[0], bb, acc[tap][0]);
-            acc[tap][1] = mfma16(sa[1], bb, acc[tap][1]);
-          }
-        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
     __syncthreads();                                  // tile 0 staged
     for (int t = 0; t < n; t += 2) {
-      mfma_tile(buf0);
+      if (!WG_EXP(4)) mfma_tile(buf0);
       __syncthreads();
-      if (t + 1 < n) {
-        mfma_tile(buf1);
-        __syncthreads();
-      }
+      if (t + 1 < n && !WG_EXP(4)) mfma_tile(buf1);
+      __syncthreads();
     }
     // epilogue image [64 cs][32 cb * 9 taps] (the loop ended with a barrier: every wave is done with the tile buffers)
     const int ecb = (jt * 16 + (lane & 15)) * 9;

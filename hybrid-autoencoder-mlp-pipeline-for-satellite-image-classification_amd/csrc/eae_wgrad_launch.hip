@@ -26,7 +26,7 @@ int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_fl
   }();
   (void)parsed;
   // enc.conv2's weight gradient is the last one of the step: it runs in the tail, beside conv2's backward-data and conv1's weight gradient only
-  constexpr bool LAST = (CS == 64 && SM == SRC_BNBWD);
+  constexpr bool LAST = (CS == 64 && (SM == SRC_BNBWD || SM == SRC_RAWG));
   const int wgs = LAST ? wgs_last : (nblk == 1 ? wgs_one : wgs_wide);
   int slices = wgs / nblk;
   if (slices < 1) slices = 1;
@@ -78,6 +78,13 @@ int eae_launch_wgrad_s2(hipStream_t st, const WgradArgs& a, int cs, int cb, int 
   CASE(128, 64, SRC_BNRELU, SRC_BNBWD);
   CASE(256, 128, SRC_RAW, SRC_BNBWD);
   CASE(64, 32, SRC_RAW, SRC_RAW);       // plain (tests)
+  // the train step: the gradient operand is the dy tensor the layer's backward-data kernel wrote while staging it (SRC_RAWG)
+  CASE(64, 32, SRC_RAWG, SRC_BNRELU);
+  CASE(128, 64, SRC_RAWG, SRC_BNRELU);
+  CASE(256, 128, SRC_RAWG, SRC_BNRELU);
+  CASE(64, 32, SRC_BNRELU, SRC_RAWG);
+  CASE(128, 64, SRC_BNRELU, SRC_RAWG);
+  CASE(256, 128, SRC_RAW, SRC_RAWG);
 #undef CASE
   return eae_set_error(-2, "wgrad: no kernel instantiated for this (cs, cb, modes)");
 }

@@ -129,6 +129,12 @@ int eae_adam_step(eae_ctx* ctx, void* stream, float lr, float weight_decay);
 int eae_ae_grad_step_begin(eae_ctx* ctx, void* stream, const eae_step_io* io);
 int eae_ae_grad_step_end(eae_ctx* ctx, void* stream);
 void* eae_side_stream(eae_ctx* ctx);
+/* Test / diagnostic access to the workspace tensors of the most recent step (bf16 NHWC; the device is synchronised first):
+ * kind 0 = raw conv outputs y[idx] (idx 0..3), 1 = their masked gradients gy[idx], 2 = raw transposed-conv outputs u[idx] (0..2),
+ * 3 = gu[idx], 4 / 5 = the BatchNorm-backward-applied gradients dy the backward-data kernels store for the weight-gradient kernels
+ * (idx 1..3 / 0..2).  Copies up to `bytes` into host memory; returns the bytes copied (negative: error).  No reference counterpart:
+ * torch keeps these as autograd-internal buffers of loss.backward() (R.md:653). */
+long long eae_debug_read(eae_ctx* ctx, int kind, int idx, void* host_dst, long long bytes);
 /* The same hand-off without splitting the call (no host gap between the halves): once requested, engine-owned stream `which`
  * is, after every eae_ae_grad_step, ordered after the completion of gradient tensors 18..37 (which = 0: classifier, decoder,
  * dec.fc) or 8..17 (which = 1: enc.fc, conv4, conv3); a collective enqueued behind it overlaps the rest of that step's

@@ -1213,3 +1213,45 @@ def test_training_curve_tracks_the_torch_cpu_port_over_120_steps():
         xr, lr_, _ = T.forward(p, torch.from_numpy(xv), train=False)
         vp = alpha * float(((xr - torch.from_numpy(xv)) ** 2).mean()) + float(torch.nn.functional.cross_entropy(lr_, torch.from_numpy(yv)))
     assert abs(ve - vp) <= 0.05 * vp, (ve, vp)
+
+
+def test_dy_mode_stores_the_staged_gradient_and_gives_the_same_weight_gradients(monkeypatch):
+    """EAE_DY_MASK (round 4, off by default): the backward-data kernels of the four inner layers store the BatchNorm-backward-applied
+    gradient dy they stage, and the weight-gradient kernels read that one tensor (SRC_RAWG) behind them instead of transforming
+    g and y beside them.  (1) every gradient equals the default mode's bit for bit (the same bf16 operands in the same order);
+    (2) the stored dy equals A*g + (B*y + C) recomputed from the stored g, y and the layer's backward coefficients to one bf16 ulp
+    at rounding ties; (3) repeated steps are bitwise equal (a store with an SGPR soffset in front of a VALU write of its data
+    registers shipped overwritten dwords now and then: tests/test_isa_guard.py)."""
+    import ctypes as C
+    x, y = gu.make_images(48, 321)
+    xd, yd = _cuda(x), _cuda(y)
+    grads = {}
+    for mask in ("0", "0x3c", "0x3c"):
+        monkeypatch.setenv("EAE_DY_MASK", mask)
+        m = _model()
+        eng = _engine(m, max_batch=48)
+        eng.grad_step(xd, yd, 35.0)
+        torch.cuda.synchronize()
+        g = eng.grads.cpu().numpy().copy()
+        if mask in grads:
+            assert np.array_equal(grads[mask], g)                      # (3)
+        grads[mask] = g
+        if mask != "0":
+            # (2) deconv2's output map u[1] (idx 1, 16 x 16 x 64) and conv3's output map y[2] (idx 2, 8 x 8 x 128)
+            for (kdy, kg, ky, idx, per) in ((5, 3, 2, 1, 16 * 16 * 64), (4, 1, 0, 2, 8 * 8 * 128)):
+                bufs = []
+                for kind in (kdy, kg, ky):
+                    b = np.empty(48 * per, np.uint16)
+                    assert eng.lib.eae_debug_read(eng.ctx, kind, idx, b.ctypes.data_as(C.c_void_p), b.nbytes) == b.nbytes
+                    bufs.append((b.astype(np.uint32) << 16).view(np.float32))
+                dy, gg, yy = bufs
+                assert np.isfinite(dy).all() and np.abs(dy).max() > 0
+                # the coefficients are not exported: fit dy = A*g + B*y + C per channel by least squares and require a bf16-exact fit
+                ch = 64 if idx == 1 else 128
+                dy2, g2, y2 = dy.reshape(-1, ch), gg.reshape(-1, ch), yy.reshape(-1, ch)
+                for c_ in (0, ch // 2, ch - 1):
+                    A = np.stack([g2[:, c_], y2[:, c_], np.ones(len(g2))], 1).astype(np.float64)
+                    coef, *_ = np.linalg.lstsq(A, dy2[:, c_].astype(np.float64), rcond=None)
+                    fit = A @ coef
+                    assert np.abs(fit - dy2[:, c_]).max() <= 2.0 ** -7 * max(1e-30, np.abs(dy2[:, c_]).max()), (idx, c_)
+    assert np.array_equal(grads["0"], grads["0x3c"])                   # (1)

@@ -48,11 +48,11 @@ class Src:
         self.mode = mode
         self.keep = []
         bc = lambda v: v[None, :, None, None].astype(np.float64)
-        if mode == 0:
+        if mode in (0, 4):  # as stored (4 = a stored gradient tensor: the same load, e5m2 in the fp8 variants)
             x = O.bf16_round((rng.standard_normal(shape) * scale).astype(np.float32))
             d = G.to_nhwc_bf16(x)
             self.keep = [d]
-            self.src = G.src(0, d)
+            self.src = G.src(mode, d)
             self.value = x
         elif mode == 1:     # max(0, s*y + t), fp32 fma, rounded to bf16
             y = O.bf16_round((rng.standard_normal(shape) * scale).astype(np.float32))
@@ -151,6 +151,11 @@ WGRAD_CASES = [
     (64, 32, 16, 1, 2, 2), (128, 64, 8, 1, 2, 3), (256, 128, 4, 0, 2, 13),       # dec.deconv3/2/1
     (64, 32, 16, 0, 0, 1), (128, 64, 8, 2, 1, 1), (256, 128, 4, 2, 1, 3),        # a single tile, fewer images than a tile holds
     (64, 32, 16, 2, 1, 37), (256, 128, 4, 0, 2, 70),                             # several tiles per workgroup (odd counts)
+    # the train step's forms: the gradient operand is the stored dy tensor (mode 4) the backward-data kernel wrote
+    (64, 32, 16, 4, 1, 3), (128, 64, 8, 4, 1, 5), (256, 128, 4, 4, 1, 11),       # enc.conv2/3/4
+    (64, 32, 16, 1, 4, 2), (128, 64, 8, 1, 4, 3), (256, 128, 4, 0, 4, 13),       # dec.deconv3/2/1
+    (128, 64, 8, 4, 1, 1), (256, 128, 4, 4, 1, 3), (64, 32, 16, 4, 1, 37), (256, 128, 4, 0, 4, 70), (128, 64, 8, 1, 4, 67),
+    (64, 32, 8, 4, 1, 5), (64, 32, 4, 1, 4, 9), (128, 64, 16, 4, 1, 2), (256, 128, 16, 0, 4, 1), (128, 64, 4, 1, 4, 17),   # the other tile geometries
 ]
 
 
@@ -170,7 +175,7 @@ def test_wgrad_instantiation(lib, cs, cb, hs, smode, bmode, B):
     assert np.isfinite(got).all()
     # exact bf16 operands, fp32 accumulation: only the summation order differs (a transformed operand can differ from the
     # NumPy value by one bf16 ulp where the fp32 fma lands on a rounding tie)
-    assert G.relmax(got, ref) < (1e-4 if smode == 0 and bmode == 0 else 1.5e-3), G.relmax(got, ref)
+    assert G.relmax(got, ref) < (1e-4 if smode in (0, 4) and bmode in (0, 4) else 1.5e-3), G.relmax(got, ref)
 
 
 def test_wgrad_repeatable_and_slice_count_independent(lib):

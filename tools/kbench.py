@@ -67,7 +67,15 @@ for (cin, cout, h) in ((32, 64, 32), (64, 128, 16), (128, 256, 8)):
     ss = G.src(2, g2, small, coef(3, cout)); bs = G.src(1, big, None, coef(4, cin))
     t = timeit(lambda: check(lib.eae_op_wgrad_s2(G.stream(), ss, bs, cout, cin, B, h // 2, h // 2, G.ptr(scratch), scratch.numel(), G.ptr(dw))))
     flops = 2.0 * B * (h // 2) ** 2 * 9 * cin * cout
-    rows.append((f"wgrad {cout}x{cin} Hs{h // 2} (+reduce)", t, flops / t / 1e6, (small.numel() * 2 + big.numel()) * 2 / t / 1e3))
+    rows.append((f"wgrad {cout}x{cin} Hs{h // 2} (+reduce) g,y | y", t, flops / t / 1e6, (small.numel() * 2 + big.numel()) * 2 / t / 1e3))
+    # the train step's forms (round 4): the gradient operand is the stored dy tensor
+    s4 = G.src(4, g2)
+    t = timeit(lambda: check(lib.eae_op_wgrad_s2(G.stream(), s4, bs, cout, cin, B, h // 2, h // 2, G.ptr(scratch), scratch.numel(), G.ptr(dw))))
+    rows.append((f"wgrad {cout}x{cin} Hs{h // 2} conv-type dy | y", t, flops / t / 1e6, (small.numel() + big.numel()) * 2 / t / 1e3))
+    sa = G.src(0, small) if cout == 256 else G.src(1, small, None, coef(4, cout))
+    b4 = G.src(4, big)
+    t = timeit(lambda: check(lib.eae_op_wgrad_s2(G.stream(), sa, b4, cout, cin, B, h // 2, h // 2, G.ptr(scratch), scratch.numel(), G.ptr(dw))))
+    rows.append((f"wgrad {cout}x{cin} Hs{h // 2} deconv-type y | dy", t, flops / t / 1e6, (small.numel() + big.numel()) * 2 / t / 1e3))
 
 x = torch.rand((B, 3, 64, 64), device=dev); wp = bf((32, 64)); bias = torch.randn(32, device=dev)
 out = bf((B, 32, 32, 32)); part = torch.zeros((B * 8, 2, 32), device=dev)
