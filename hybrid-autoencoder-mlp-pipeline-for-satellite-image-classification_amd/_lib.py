@@ -58,6 +58,8 @@ _PROTOS = {
     "eae_debug_read": (C.c_longlong, [vp, C.c_int, C.c_int, vp, C.c_longlong]),
     "eae_dp_stream": (vp, [vp, C.c_int]),
     "eae_adam_step_scaled": (C.c_int, [vp, vp, C.c_float, C.c_float, C.c_float]),
+    "eae_dp_local_bad": (C.c_int, [vp, vp, vp]),
+    "eae_adam_step_dp": (C.c_int, [vp, vp, C.c_float, C.c_float, C.c_float, vp]),
     "eae_dp_unique_id": (C.c_int, [vp]),
     "eae_dp_init": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "eae_dp_world": (C.c_int, [vp]),

@@ -11,6 +11,8 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <chrono>
+#include <thread>
 
 static thread_local std::string g_err;
 int eae_set_error(int code, const char* msg) { g_err = msg ? msg : "unknown error"; return code; }
@@ -151,6 +153,7 @@ struct eae_ctx {
   // plain tensor, or does the weight gradient transform g and y itself and run BESIDE the backward-data kernel?  bit i (1..3) =
   // enc.conv(i+1), bit 4 + i (0..2) = dec.deconv(i+1).  EAE_DY_MASK overrides (diagnostic A/B).
   unsigned dy_mask = 0;
+  int nan_exact = 0;               // EAE_NAN_EXACT=1: a diverged step writes NaN into every parameter and moment like the reference's does
   bool skip_wgrad = false;         // EAE_SKIP_WGRAD=1 (diagnostic): the six 3x3 weight gradients are not launched (main chain alone)
   bool use_gates = true;           // device-side gates instead of event records on the caller's stream (EAE_FORK_EVENTS=1: events)
   unsigned long long gate_limit = 3000000000ULL;     // gate spin bound in 100 MHz ticks (30 s; EAE_GATE_TIMEOUT_MS, 0 = unbounded)
@@ -371,6 +374,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   // layers' backward-data kernels are built without the store (eae_igemm.hip.h: DY), so bits 1 and 6 are never honoured.
   c->dy_mask = (getenv("EAE_DY_MASK") ? (unsigned)strtoul(getenv("EAE_DY_MASK"), nullptr, 0) : 0u) & 0x3cu;
   c->skip_wgrad = getenv("EAE_SKIP_WGRAD") != nullptr;
+  c->nan_exact = (getenv("EAE_NAN_EXACT") && atoi(getenv("EAE_NAN_EXACT")) != 0) ? 1 : 0;
   c->fold_fwd = getenv("EAE_NO_FOLD_FWD") == nullptr;
   c->fold_bwd = getenv("EAE_NO_FOLD_BWD") == nullptr;
   if (e != hipSuccess) { hipFree(c->ws); delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
@@ -1311,8 +1315,10 @@ extern "C" int eae_fp8_scales(eae_ctx* c, float* out18) {
 extern "C" int eae_adam_step(eae_ctx* c, void* stream, float lr, float weight_decay) {
   if (!c || !c->P || !c->G || !c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: parameter, gradient and moment arenas must be bound");
   c->adam_step += 1;
+  float* const ll = c->last_loss;
+  c->last_loss = nullptr;            // the step's loss_last buffer is the caller's: it is written (NaN, when the update is refused) by THIS launch only
   RC(eae_launch_adam_scaled((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step, 1.0f,
-                            c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss));
+                            c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), ll, c->nan_exact));
   c->packed = false; c->acc_clean = true; c->bwd_dirty = false;
   return 0;
 }
@@ -1363,8 +1369,10 @@ extern "C" void* eae_dp_stream(eae_ctx* c, int which) {
 extern "C" int eae_adam_step_scaled(eae_ctx* c, void* stream, float lr, float weight_decay, float grad_scale) {
   if (!c || !c->P || !c->G || !c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: parameter, gradient and moment arenas must be bound");
   c->adam_step += 1;
+  float* const ll = c->last_loss;
+  c->last_loss = nullptr;            // (see eae_adam_step)
   RC(eae_launch_adam_scaled((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step, grad_scale,
-                            c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss));
+                            c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), ll, c->nan_exact));
   c->packed = false; c->acc_clean = true; c->bwd_dirty = false;
   return 0;
 }
@@ -1393,15 +1401,19 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
     if (!ent && c->ngraphs < eae_ctx::NGRAPH) { ent = &c->graphs[c->ngraphs++]; ent->key = key; }
     if (ent) ent->seen++;
   }
-  c->adam_step += 1;
   if (!ent) {      // plain eager step: Adam takes its bias-correction scalars by value (one launch less on the critical path)
     int rc = forward_impl(c, st, io, true);
     if (!rc) rc = backward_impl(c, st, io);
-    if (!rc) rc = eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f,
-                                         c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss);
+    if (!rc) {
+      c->adam_step += 1;             // (behind the launches that can fail: a failed step must not advance the bias correction)
+      rc = eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f,
+                                  c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss, c->nan_exact);
+    }
+    c->last_loss = nullptr;
     c->packed = false; c->acc_clean = (rc == 0); c->bwd_dirty = !c->acc_clean;
     return rc;
   }
+  c->adam_step += 1;
   RC(eae_launch_set_dyn(st, c->dyn, lr, 0.9, 0.999, 0.0, c->adam_step));
   if (ent && ent->exec) {
     EAE_HIP(hipGraphLaunch(ent->exec, st));
@@ -1531,6 +1543,12 @@ struct RcclApi {
   decltype(&ncclAllReduce) allReduce = nullptr;
   decltype(&ncclBroadcast) broadcast = nullptr;
   decltype(&ncclGetErrorString) getErrorString = nullptr;
+  // optional (older libraries lack them): grouped launches, time-bounded communicator bring-up
+  decltype(&ncclGroupStart) groupStart = nullptr;
+  decltype(&ncclGroupEnd) groupEnd = nullptr;
+  decltype(&ncclCommInitRankConfig) commInitRankConfig = nullptr;
+  decltype(&ncclCommGetAsyncError) commGetAsyncError = nullptr;
+  decltype(&ncclCommAbort) commAbort = nullptr;
   std::string err;
 };
 RcclApi* rccl_api() {
@@ -1548,6 +1566,11 @@ RcclApi* rccl_api() {
     a.broadcast = reinterpret_cast<decltype(a.broadcast)>(dlsym(a.h, "ncclBroadcast"));
     a.getErrorString = reinterpret_cast<decltype(a.getErrorString)>(dlsym(a.h, "ncclGetErrorString"));
     if (!a.getUniqueId || !a.commInitRank || !a.commDestroy || !a.allReduce || !a.broadcast || !a.getErrorString) a.err = "librccl lacks a required symbol";
+    a.groupStart = reinterpret_cast<decltype(a.groupStart)>(dlsym(a.h, "ncclGroupStart"));
+    a.groupEnd = reinterpret_cast<decltype(a.groupEnd)>(dlsym(a.h, "ncclGroupEnd"));
+    a.commInitRankConfig = reinterpret_cast<decltype(a.commInitRankConfig)>(dlsym(a.h, "ncclCommInitRankConfig"));
+    a.commGetAsyncError = reinterpret_cast<decltype(a.commGetAsyncError)>(dlsym(a.h, "ncclCommGetAsyncError"));
+    a.commAbort = reinterpret_cast<decltype(a.commAbort)>(dlsym(a.h, "ncclCommAbort"));
     return a;
   }();
   return &api;
@@ -1577,7 +1600,31 @@ extern "C" int eae_dp_init(eae_ctx* c, int rank, int world, const void* id128) {
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   ncclComm_t comm = nullptr;
-  RCCL(r->commInitRank(&comm, world, id, rank), "ncclCommInitRank");
+  // Time-bounded bring-up (EAE_DP_INIT_TIMEOUT_S, default 120; 0 = blocking call): ncclCommInitRank is a rendezvous of all ranks and
+  // blocks for ever when a peer never arrives.  With the non-blocking configuration the call returns at once and the communicator is
+  // polled until it is ready, fails, or the time is up -- then it is aborted and the caller falls back (dp.py: every rank together).
+  static const double limit_s = getenv("EAE_DP_INIT_TIMEOUT_S") ? atof(getenv("EAE_DP_INIT_TIMEOUT_S")) : 120.0;
+  if (limit_s > 0 && r->commInitRankConfig && r->commGetAsyncError) {
+    ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+    cfg.blocking = 0;
+    ncclResult_t e = r->commInitRankConfig(&comm, world, id, rank, &cfg);
+    if (e != ncclSuccess && e != ncclInProgress) return rccl_fail(r, e, "ncclCommInitRankConfig");
+    const auto t0 = std::chrono::steady_clock::now();
+    ncclResult_t st_ = ncclInProgress;
+    while (true) {
+      e = r->commGetAsyncError(comm, &st_);
+      if (e != ncclSuccess) { if (r->commAbort) r->commAbort(comm); return rccl_fail(r, e, "ncclCommGetAsyncError"); }
+      if (st_ != ncclInProgress) break;
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
+        if (r->commAbort) r->commAbort(comm);
+        return eae_set_error(EAE_ERR_STATE, "dp_init: the communicator did not come up within EAE_DP_INIT_TIMEOUT_S (a peer never joined?)");
+      }
+      std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+    if (st_ != ncclSuccess) { if (r->commAbort) r->commAbort(comm); return rccl_fail(r, st_, "ncclCommInitRankConfig (asynchronous)"); }
+  } else {
+    RCCL(r->commInitRank(&comm, world, id, rank), "ncclCommInitRank");
+  }
   c->dp_comm = comm; c->dp_rank = rank; c->dp_world = world;
   if (!c->ev_dp_done) EAE_HIP(hipEventCreateWithFlags(&c->ev_dp_done, EV_FLAGS));
   return 0;
@@ -1609,6 +1656,37 @@ extern "C" int eae_dp_broadcast(eae_ctx* c, void* stream, void* buf, long long b
   c->packed = false;
   return 0;
 }
+// The "optimizer refuses to update" switches (a gate that timed out: sticky; a non-finite BatchNorm statistic: this step) are local to a
+// rank, but a synchronous data-parallel step must take the decision for ALL ranks or the replicas diverge silently: every
+// rank publishes (timeout | poison) != 0 into one device word, the word is max-reduced over the ranks next to the last gradient bucket
+// (one grouped launch where the library has ncclGroupStart), and the optimizer kernel reads the REDUCED word.
+static __global__ EAE_NO_PK void dp_flag_kernel(const unsigned* a, const unsigned* b, unsigned* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {      // out[0]: stale (gate time-out), out[1]: diverged (non-finite statistics) -- kept apart:
+    out[0] = (a != nullptr && __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1u : 0u;      // the optimizer
+    out[1] = (b != nullptr && __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1u : 0u;      // treats them differently
+  }
+}
+// sigwords[12..13]: this rank's two flags, then the reduced ones (same words, all-reduced in place)
+static unsigned* dp_flag_word(eae_ctx* c) { return c->sigwords + 12; }
+extern "C" int eae_dp_local_bad(eae_ctx* c, void* stream, unsigned* out_dev) {
+  if (!c || !out_dev) return eae_set_error(EAE_ERR_ARG, "dp_local_bad: NULL argument");
+  hipLaunchKernelGGL(dp_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c->sigwords + 8, poison_word(c), out_dev);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+// optimizer.step() of a data-parallel replica whose peers' flags were reduced by the caller (torch.distributed path): `peer_bad` is a
+// pair of device words (stale, diverged), non-zero = some rank must not update -> no rank updates
+extern "C" int eae_adam_step_dp(eae_ctx* c, void* stream, float lr, float weight_decay, float grad_scale, const unsigned* peer_bad) {
+  if (!c || !c->P || !c->G || !c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: parameter, gradient and moment arenas must be bound");
+  c->adam_step += 1;
+  int rc = eae_launch_adam_scaled((hipStream_t)stream, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, weight_decay, c->adam_step,
+                                  grad_scale, c->acc_base, (long long)c->poison_off, peer_bad ? peer_bad : c->sigwords + 8,
+                                  peer_bad ? peer_bad + 1 : poison_word(c), c->last_loss, c->nan_exact);
+  c->last_loss = nullptr;            // (see eae_adam_step)
+  c->packed = false; c->acc_clean = (rc == 0); c->bwd_dirty = !c->acc_clean;
+  return rc;
+}
+
 extern "C" int eae_ae_dp_train_step(eae_ctx* c, void* stream, const eae_step_io* io, float lr, int overlap) {
   RC(check_io(c, io, true));
   if (!c->dp_comm) return eae_set_error(EAE_ERR_STATE, "dp_train_step: eae_dp_init has not been called");
@@ -1616,20 +1694,33 @@ extern "C" int eae_ae_dp_train_step(eae_ctx* c, void* stream, const eae_step_io*
   hipStream_t st = (hipStream_t)stream;
   const bool ov = overlap != 0 && c->use_side;
   if (ov && !eae_dp_stream(c, 0)) return eae_set_error(EAE_ERR_HIP, "dp_train_step: cannot create the hand-off stream");
-  c->adam_step += 1;
   RC(forward_impl(c, st, io, true));
   RC(backward_impl(c, st, io));             // with a hand-off stream: dp_stream[0] is now ordered after gradient tensors 18..37
+  c->adam_step += 1;                        // (behind the launches that can fail: a failed step must not advance the bias correction)
   const long long cut = c->poff[18], total = c->poff[38];
+  RcclApi* r = rccl_api();
+  unsigned* flag = dp_flag_word(c);
+  hipLaunchKernelGGL(dp_flag_kernel, dim3(1), dim3(64), 0, st, c->sigwords + 8, poison_word(c), flag);
+  EAE_LAUNCH_CHECK();
+  const bool grp = r->groupStart && r->groupEnd;
   if (ov) {
     RC(eae_dp_allreduce_bucket(c, c->dp_stream[0], cut, total - cut));
     EAE_HIP(hipEventRecord(c->ev_dp_done, c->dp_stream[0]));
-    RC(eae_dp_allreduce_bucket(c, st, 0, cut));
-    EAE_HIP(hipStreamWaitEvent(st, c->ev_dp_done, 0));
-  } else {
-    RC(eae_dp_allreduce_bucket(c, st, 0, total));
   }
+  if (grp) RCCL(r->groupStart(), "ncclGroupStart");
+  {
+    int rc = eae_dp_allreduce_bucket(c, st, 0, ov ? cut : total);
+    if (!rc) {
+      ncclResult_t e = r->allReduce(flag, flag, 2, ncclUint32, ncclMax, static_cast<ncclComm_t>(c->dp_comm), st);
+      if (e != ncclSuccess) rc = rccl_fail(r, e, "ncclAllReduce (flag)");
+    }
+    if (grp) { ncclResult_t e = r->groupEnd(); if (!rc && e != ncclSuccess) rc = rccl_fail(r, e, "ncclGroupEnd"); }
+    RC(rc);
+  }
+  if (ov) EAE_HIP(hipStreamWaitEvent(st, c->ev_dp_done, 0));
   RC(eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f / (float)c->dp_world,
-                            c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss));
+                            c->acc_base, (long long)c->poison_off, flag, flag + 1, c->last_loss, c->nan_exact));
+  c->last_loss = nullptr;
   c->packed = false; c->acc_clean = true; c->bwd_dirty = false;
   return 0;
 }

@@ -470,14 +470,25 @@ void eae_fp8_state_init(Fp8State* h) {
 __global__ EAE_NO_PK __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n4, float b1, float b2, float step_size,
                                                     float bc2_sqrt, float eps, float wd, float gscale, uint4* __restrict__ zbuf, long zn16,
-                                                    const unsigned* __restrict__ bad, const unsigned* __restrict__ bad2, float* __restrict__ nan_out) {
+                                                    const unsigned* __restrict__ bad, const unsigned* __restrict__ bad2, float* __restrict__ nan_out,
+                                                    int nan_fill) {
   // side job: clear the BatchNorm statistics accumulators for the next step (every consumer of this step has finished)
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zn16; i += (long)gridDim.x * 256) zbuf[i] = make_uint4(0, 0, 0, 0);
   // a side-stream gate of this context has timed out at some point (sticky word): gradients may have been computed from stale
   // activations -- no update, and the step's loss scalars become NaN so that the run cannot go on unnoticed
-  if ((bad != nullptr && __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ||
-      (bad2 != nullptr && __hip_atomic_load(bad2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+  const bool stale = bad != nullptr && __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  const bool diverged = bad2 != nullptr && __hip_atomic_load(bad2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  if (stale || diverged) {
     if (nan_out != nullptr && blockIdx.x == 0 && threadIdx.x < 3) nan_out[threadIdx.x] = __builtin_nanf("");
+    // nan_fill (eae_config.nan_exact / EAE_NAN_EXACT=1): a DIVERGED step does to the replica what it does to the reference's model --
+    // loss.backward() on a non-finite loss hands every parameter a NaN gradient and Adam writes NaN into the parameter and both moments
+    // (R.md:653-654); the default leaves the last finite parameters in place.  Never for a stale step.
+    if (nan_fill && diverged && !stale) {
+      const float4 nn = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+      for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        reinterpret_cast<float4*>(p)[i] = nn; reinterpret_cast<float4*>(m)[i] = nn; reinterpret_cast<float4*>(v)[i] = nn;
+      }
+    }
     return;
   }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -557,14 +568,14 @@ int eae_launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v
 
 int eae_launch_adam_scaled(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
                            double eps, double wd, long long step, float gscale, void* zero_buf, long long zero_bytes,
-                           const unsigned* bad, const unsigned* bad2, float* nan_out) {
+                           const unsigned* bad, const unsigned* bad2, float* nan_out, int nan_fill) {
   if (n % 4) return eae_set_error(-2, "adam: arena length must be a multiple of 4");
   double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
   long n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4, (float)b1, (float)b2, (float)(lr / bc1),
-                     (float)sqrt(bc2), (float)eps, (float)wd, gscale, (uint4*)zero_buf, (long)(zero_bytes / 16), bad, bad2, nan_out);
+                     (float)sqrt(bc2), (float)eps, (float)wd, gscale, (uint4*)zero_buf, (long)(zero_bytes / 16), bad, bad2, nan_out, nan_fill);
   EAE_LAUNCH_CHECK();
   return 0;
 }

@@ -5,13 +5,18 @@ Every rank holds a full replica (1.3 M parameters) and a shard of the global min
 arena (5.26 MB) is all-reduced in a few large buckets and divided by the world size, then the fused Adam runs on every
 rank (identical updates keep the replicas in sync).  BatchNorm uses per-rank batch statistics (DDP semantics).
 
-The collective goes through ``torch.distributed`` so that the same code runs on RCCL (GPU) and gloo (CPU tests).
+Two exchanges: the ENGINE's own RCCL communicator (``eae_dp_init`` / ``eae_ae_dp_train_step``: forward, backward, all-reduce and
+Adam enqueued by one C call; the default on the nccl backend, ``EAE_DP_NATIVE=0`` switches it off), and ``torch.distributed`` (gloo
+in the CPU tests, engines without a C context, the fall-back when the engine's communicator cannot be brought up on EVERY rank).
 
-Default exchange: ONE all-reduce of the whole arena after the backward (``EAE_DP_OVERLAP=0`` semantics).  ``EAE_DP_OVERLAP=1``
-hands the decoder-side bucket to RCCL while the encoder half of the backward is still running; it stays
-opt-in until it has run on more than one rank: the repo's co-residency finding (wrong low lanes of ``v_pk_*_f32 op_sel:``
-forms beside MFMA kernels) rests on black-box A/B runs, and although RCCL's gfx950 code contains no such instruction
-(``build.scan_packed_fp32_rccl``: 325 packed-FP32 instructions, 0 with ``op_sel:``) that is evidence, not validation.
+Default on both: ONE all-reduce of the whole arena strictly after the backward.  ``EAE_DP_OVERLAP=1`` hands the decoder-side bucket
+to RCCL while the encoder half of the backward is still running; it stays opt-in until it has run on more than
+one rank (one communicator driven from two streams, the hand-off covering tensors written on the side streams), and it is switched
+off with ``sync_bn=True`` (SyncBN's collectives of the encoder backward would run beside the engine's bucket on another communicator).
+
+The decision "no update this step" (a timed-out side-stream gate, a non-finite BatchNorm statistic) is taken for all ranks together:
+the flag word is max-reduced with the gradients, and ``DPAEStepper.end`` all-reduces the gate word with the epoch scalars so that every
+rank raises in the same place.
 
 ``sync_bn=True`` sums the BatchNorm batch statistics over the replicas (forward: the fixed-point accumulators, exact; backward:
 the fp64 sums), so that R ranks x B/R images reproduce one rank x B images; the default keeps per-rank statistics.
@@ -98,56 +103,87 @@ class DataParallelTrainer:
         if native and hasattr(engine, "ctx") and dist.get_backend(process_group) == "nccl":
             self._init_native_checked()
 
-    def _init_native_checked(self):
-        """Join the engine's communicator, then prove it on a known vector (rank r contributes r + 1 to 64 gradient words) before it is
-        trusted with real gradients.  Every rank learns whether EVERY rank succeeded (one torch all-reduce of a flag): on any failure
-        all ranks fall back to the torch.distributed exchange together -- a half-native group would hang in its first collective."""
-        import ctypes as C
-        from .engine import _stream
-        eng = self.eng
-        ok, why = 1, ""
-        try:
-            self._init_native()
-            keep = eng.grads[:64].clone()
-            eng.grads[:64] = float(self.rank + 1)
-            with torch.cuda.device(eng.device):
-                rc = int(eng.lib.eae_dp_allreduce_bucket(eng.ctx, _stream(), C.c_longlong(0), C.c_longlong(64)))
-            torch.cuda.synchronize(eng.device)
-            want = self.world * (self.world + 1) / 2.0
-            if rc != 0 or not bool((eng.grads[:64] == want).all()):
-                ok, why = 0, f"self-check of the engine's all-reduce failed (rc {rc}, got {float(eng.grads[0])}, want {want})"
-            eng.grads[:64] = keep
-        except Exception as e:      # a missing librccl symbol, a refused communicator, ...
-            ok, why = 0, f"{type(e).__name__}: {e}"
-        flag = torch.tensor([ok], dtype=torch.int32, device=eng.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
-        if int(flag.item()) != 1:
-            if why:
-                print(f"[eae dp] rank {self.rank}: engine-owned RCCL exchange unavailable ({why}); using torch.distributed", file=sys.stderr, flush=True)
-            try:
-                eng.lib.eae_dp_destroy(eng.ctx)
-            except Exception:
-                pass
-            self.native = False
+    def _agree(self, ok):
+        """Every rank learns whether EVERY rank is ok: ONE all-reduce(MIN) of a flag, issued by every rank whatever failed locally."""
+        f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.eng.device)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN, group=self.pg)
+        return int(f.item()) == 1
 
-    def _init_native(self):
+    def _init_native_checked(self):
+        """Bring up the engine's communicator and prove it on a known vector before it is trusted with real gradients.  The sequence
+        of torch collectives is IDENTICAL on every rank whatever fails locally (a rank that raised in front of a broadcast
+        while its peers sat in it, or good ranks spinning in the self-check all-reduce a failed rank never entered, hung the group):
+          0. agree: does every rank already own a communicator of this size?  (all or nothing)
+          1. every rank checks locally that it can reach RCCL (eae_dp_unique_id: dlopen + symbols; cannot block); rank 0's id is
+             broadcast -- zeroed if rank 0 failed -- and the ranks agree on "everybody can";
+          2. only then every rank calls eae_dp_init (a rendezvous inside RCCL, time-bounded by EAE_DP_INIT_TIMEOUT_S); agree;
+          3. only if every rank joined: all-reduce of rank + 1 over 64 gradient words; agree on the result.
+        Any "no" sends ALL ranks to the torch.distributed exchange together."""
         import ctypes as C
         from ._lib import check
+        from .engine import _stream
         eng = self.eng
-        if int(eng.lib.eae_dp_world(eng.ctx)) == self.world:       # the engine already belongs to a communicator of this size
-            self.native = True
-            return
-        idbuf = (C.c_ubyte * 128)()
-        t = torch.zeros(128, dtype=torch.uint8, device=eng.device)
-        if self.rank == 0:
-            check(eng.lib.eae_dp_unique_id(idbuf))
-            t.copy_(torch.tensor(list(idbuf), dtype=torch.uint8))
-        src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
-        dist.broadcast(t, src=src, group=self.pg)
-        raw = bytes(t.cpu().tolist())
-        with torch.cuda.device(eng.device):
-            check(eng.lib.eae_dp_init(eng.ctx, self.rank, self.world, raw))
-        self.native = True
+        why = []
+
+        def attempt(fn, what):
+            try:
+                fn()
+                return True
+            except Exception as e:      # a missing librccl symbol, a refused communicator, ...
+                why.append(f"{what}: {type(e).__name__}: {e}")
+                return False
+
+        def on_dev(fn):
+            if eng.device.type == "cuda":
+                with torch.cuda.device(eng.device):
+                    return fn()
+            return fn()
+
+        have = [False]
+        attempt(lambda: have.__setitem__(0, int(eng.lib.eae_dp_world(eng.ctx)) == self.world), "eae_dp_world")
+        joined = self._agree(have[0])
+        if not joined:
+            idbuf = (C.c_ubyte * 128)()
+
+            def preflight():
+                if int(eng.lib.eae_dp_world(eng.ctx)) != 0:          # a communicator of another size (or a half-agreed one): drop it
+                    on_dev(lambda: eng.lib.eae_dp_destroy(eng.ctx))
+                check(eng.lib.eae_dp_unique_id(idbuf))
+            can = attempt(preflight, "eae_dp_unique_id")
+            t = torch.zeros(128, dtype=torch.uint8, device=eng.device)
+            if self.rank == 0 and can:
+                t.copy_(torch.tensor(list(idbuf), dtype=torch.uint8))
+            src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
+            dist.broadcast(t, src=src, group=self.pg)               # ALWAYS (zeros when rank 0 could not draw an id)
+            if self._agree(can):
+                raw = bytes(t.cpu().tolist())
+                ok = attempt(lambda: on_dev(lambda: check(eng.lib.eae_dp_init(eng.ctx, self.rank, self.world, raw))), "eae_dp_init")
+                joined = self._agree(ok)
+        proven = False
+        if joined:
+            def selfcheck():
+                keep = eng.grads[:64].clone()
+                eng.grads[:64] = float(self.rank + 1)
+                rc = on_dev(lambda: int(eng.lib.eae_dp_allreduce_bucket(eng.ctx, _stream() if eng.device.type == "cuda" else None,
+                                                                        C.c_longlong(0), C.c_longlong(64))))
+                if eng.device.type == "cuda":
+                    torch.cuda.synchronize(eng.device)
+                want = self.world * (self.world + 1) / 2.0
+                got = float(eng.grads[0])
+                good = rc == 0 and bool((eng.grads[:64] == want).all())
+                eng.grads[:64] = keep
+                if not good:
+                    raise RuntimeError(f"self-check of the engine's all-reduce failed (rc {rc}, got {got}, want {want})")
+            proven = self._agree(attempt(selfcheck, "self-check"))
+        self.native = bool(joined and proven)
+        if not self.native:
+            if why:
+                print(f"[eae dp] rank {self.rank}: engine-owned RCCL exchange unavailable ({'; '.join(why)}); using torch.distributed",
+                      file=sys.stderr, flush=True)
+            try:
+                on_dev(lambda: eng.lib.eae_dp_destroy(eng.ctx))
+            except Exception:
+                pass
 
     def rccl_ranks(self):
         """Ranks of the engine-owned RCCL communicator (0: the exchange goes through torch.distributed)."""
@@ -190,7 +226,8 @@ class DataParallelTrainer:
             from ._lib import check
             from .engine import _stream
             io, keep = eng._io(x, labels, True, head, alpha)
-            overlap = 0 if os.environ.get("EAE_DP_OVERLAP", "1") == "0" else 1
+            # opt-in, and never beside SyncBN's collectives (module docstring)
+            overlap = 1 if (os.environ.get("EAE_DP_OVERLAP", "0") == "1" and self.sync_bn is None) else 0
             with torch.cuda.device(eng.device):
                 check(eng.lib.eae_ae_dp_train_step(eng.ctx, _stream(), C.byref(io), float(lr), overlap))
             return
@@ -200,10 +237,10 @@ class DataParallelTrainer:
             self.allreduce_gradients()
             eng.adam_step(lr)
             return
-        if os.environ.get("EAE_DP_OVERLAP", "0") != "1":     # default: ONE collective strictly after the backward
+        if os.environ.get("EAE_DP_OVERLAP", "0") != "1" or self.sync_bn is not None:     # default: ONE collective strictly after the backward
             eng.grad_step(x, labels, alpha, head=head)
             dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM, group=self.pg)
-            eng.adam_step(lr, grad_scale=1.0 / self.world)
+            self._adam_together(lr)
             return
         cut = eng.poff[18]
         total = eng.poff[38]
@@ -239,7 +276,24 @@ class DataParallelTrainer:
             eng.grad_step_end()                # joins every side stream into the current stream
             dist.all_reduce(eng.grads[0:cut], op=dist.ReduceOp.SUM, group=self.pg)
             h1.wait()
-        eng.adam_step(lr, grad_scale=1.0 / self.world)
+        self._adam_together(lr)
+
+    def _adam_together(self, lr):
+        """Adam with the 1/world scale folded in; the refusal switches (gate time-out, non-finite statistics) max-reduced over the ranks
+        first, so that either every replica updates or none does (engines with the C entry points; others: plain adam_step)."""
+        eng = self.eng
+        if not (hasattr(eng, "ctx") and hasattr(eng.lib, "eae_adam_step_dp")):
+            eng.adam_step(lr, grad_scale=1.0 / self.world)
+            return
+        import ctypes as C
+        from ._lib import check
+        from .engine import _stream
+        if not hasattr(self, "_bad"):
+            self._bad = torch.zeros(2, dtype=torch.int32, device=eng.device)      # (stale, diverged)
+        with torch.cuda.device(eng.device):
+            check(eng.lib.eae_dp_local_bad(eng.ctx, _stream(), C.c_void_p(self._bad.data_ptr())))
+            dist.all_reduce(self._bad, op=dist.ReduceOp.MAX, group=self.pg)
+            check(eng.lib.eae_adam_step_dp(eng.ctx, _stream(), float(lr), 0.0, 1.0 / self.world, C.c_void_p(self._bad.data_ptr())))
 
 
 class DPAEStepper:
@@ -270,11 +324,18 @@ class DPAEStepper:
         self.eng.forward(imgs, labels=labels, train=False, head=self.head, alpha=self.alpha, want=(), accum=True)
 
     def end(self):
-        acc = self.eng.loss_accum.clone()
+        # the gate word travels WITH the epoch scalars: a rank whose side-stream gate timed out must not raise alone while its peers
+        # walk into their next collective -- every rank sees the sum and raises in the same place
+        gates = float(bool(self.eng.gate_timeouts())) if hasattr(self.eng, "gate_timeouts") else 0.0      # (synchronises; once per epoch phase)
+        acc = torch.cat([self.eng.loss_accum.detach().to(torch.float32).flatten(),
+                         torch.tensor([1.0 if gates > 0 else 0.0], dtype=torch.float32, device=self.eng.loss_accum.device)])
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.pg)
         a = acc.tolist()
         if hasattr(self.eng, "check_gates"):
-            self.eng.check_gates()      # the .tolist() above has synchronised; a timed-out side-stream gate must not go unnoticed
+            self.eng.check_gates()      # the .tolist() above has synchronised: this rank's own time-out, with its details
+        if a[-1] > 0:
+            raise RuntimeError(f"{int(a[-1])} data-parallel rank(s) reported a timed-out side-stream gate: the step's gradients may come from "
+                               "stale activations; no replica was updated (see eae_gate_timeouts, EAE_GATE_TIMEOUT_MS)")
         n = max(a[3], 1.0)
         return a[0] / n, int(a[3])
 

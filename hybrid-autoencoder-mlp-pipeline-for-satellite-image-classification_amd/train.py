@@ -169,15 +169,28 @@ def grid_search_autoencoder(train_loader, val_loader, alpha_values=(20, 25, 30, 
     `out_dir/AE_GLOBAL_BEST.pt` (plain state_dict) and `out_dir/validation_losses.json` (keys "alpha={a}, lr={lr}").
 
     concurrent=K > 1 trains K configurations at a time on the one GPU (run_concurrent): every configuration is an independent
-    engine context on its own stream, so its curves and final weights are bitwise those of the same configuration trained alone
-    (tests/test_gpu_grid.py); the log lines of a configuration are emitted together, in grid order, and the global best is chosen
-    in grid order with the reference's strict `<` -- the same winner as the sequential loop."""
+    engine context on its own stream.  With the default `fit_fn` the models are built in grid order on the CALLING thread before the
+    workers start, so under `torch.manual_seed(s)` every configuration starts from the parameters the sequential grid gives it and
+    its curves and final weights are bitwise those of the same configuration trained alone -- provided the loaders' order does not
+    depend on torch's global generator (a shuffling DataLoader draws its per-iterator seed from it, in whatever order the worker
+    threads reach it: give such a loader its own `generator=`); a custom `fit_fn` that builds its own model has to seed it itself
+    (tests/test_gpu_grid.py covers both).  The log lines of a configuration are emitted together, in grid order, and the global
+    best is chosen in grid order with the reference's strict `<` -- the same winner as the sequential loop."""
     os.makedirs(out_dir, exist_ok=True)
     fit_fn = fit_fn or fit_autoencoder
     results, best = {}, {"loss": float("inf"), "info": None, "state": None, "train": None, "val": None}
     grid = [(alpha, lr) for alpha in alpha_values for lr in lr_values]
     fitted = None
     if concurrent and int(concurrent) > 1:
+        # parameter initialisation draws from torch's global generator: K worker threads would draw in timing-dependent order (ADVICE r3)
+        prebuilt = {}
+        if fit_fn is fit_autoencoder:
+            for (alpha, lr) in grid:
+                m = SupervisedAutoencoder(latent_dim=latent_dim, num_classes=10).to(device)
+                if int(concurrent) >= 3:
+                    m._eae_side_streams = -1
+                prebuilt[(alpha, lr)] = m
+
         def job_of(alpha, lr):
             def job():
                 lines = []
@@ -185,7 +198,7 @@ def grid_search_autoencoder(train_loader, val_loader, alpha_values=(20, 25, 30, 
                 # queues.  Contexts with the default three streams each share them -- K = 2 / 4 / 8 / 16 reach 1.65x the single-configuration
                 # rate and stay there -- while ONE stream per context lets four configurations run side by side: 487 K vs 352 K images/s
                 # at K = 4.  hipGraph replay of each step is slower than eager (0.7-0.8x), more hardware queues or several processes far slower.
-                extra = {"side_streams": -1} if (int(concurrent) >= 3 and fit_fn is fit_autoencoder) else {}
+                extra = {"model": prebuilt.pop((alpha, lr))} if fit_fn is fit_autoencoder else {}
                 r = fit_fn(train_loader, val_loader, alpha, lr, latent_dim=latent_dim, num_epochs=num_epochs, patience=patience,
                            device=device, verbose=verbose, log=lines.append, **extra)
                 r = dict(r)

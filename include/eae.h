@@ -66,6 +66,11 @@ int eae_fp8_scales(eae_ctx* ctx, float* out18);
  * bn_off[14] = its length. */
 int eae_ae_layout(const eae_config* cfg, long long* param_off, long long* bn_off);
 
+/* Environment switches read by eae_create are listed in INTEGRATION.md.  One of them changes results: EAE_NAN_EXACT=1 -- a DIVERGED
+ * train step (a non-finite BatchNorm statistic was consumed: the loss scalars read NaN) writes NaN into every parameter and both Adam
+ * moments, which is what the reference's loop does to its model (loss.backward() on a non-finite loss gives every parameter a NaN
+ * gradient, torch.optim.Adam propagates it: R.md:653-654; pinned by tests/golden/ae_nan_step_b8.npz).  Default: the optimizer refuses
+ * the update and the last finite parameters stay (the run still reads as diverged through its NaN losses). */
 int eae_create(const eae_config* cfg, eae_ctx** out);
 int eae_destroy(eae_ctx* ctx);
 
@@ -104,7 +109,10 @@ typedef struct eae_step_io {
   float* logits;             /* optional [B,num_classes] fp32 */
   float* z;                  /* optional [B,latent_dim] fp32 */
   float* loss_accum;         /* optional float[8]: += loss*B, mse*B, ce*B, B, #correct  (R.md:656-657, 679-681) */
-  float* loss_last;          /* optional float[4]: loss, mse, ce of this call */
+  float* loss_last;          /* optional float[4]: loss, mse, ce of this call.  With a SEPARATE optimizer call (eae_ae_grad_step /
+                              * eae_ae_backward followed by eae_adam_step*) the pointer is kept until that ONE optimizer launch, which
+                              * writes NaN there when it refuses the update; it is dropped afterwards: keep the buffer alive until the
+                              * optimizer call of the step has been enqueued */
 } eae_step_io;
 
 /* x_hat, logits, z = model(x) (R.md:647 / 673), plus the loss terms when io->x target / labels are given. */
@@ -157,6 +165,14 @@ int eae_dp_destroy(eae_ctx* ctx);
 int eae_dp_allreduce_bucket(eae_ctx* ctx, void* stream, long long elem_off, long long count);
 int eae_dp_broadcast(eae_ctx* ctx, void* stream, void* buf, long long bytes, int root);
 int eae_ae_dp_train_step(eae_ctx* ctx, void* stream, const eae_step_io* io, float lr, int overlap);
+/* The decision "this step must not update the parameters" (a side-stream gate timed out: sticky; a non-finite BatchNorm statistic:
+ * this step) is taken for ALL replicas together, or they would diverge silently: eae_ae_dp_train_step max-reduces one flag word over
+ * the ranks next to the last gradient bucket.  For an exchange the caller runs itself (torch.distributed): eae_dp_local_bad writes this
+ * rank's TWO flags (stale, diverged; 0 / 1 each) to a pair of device words on `stream`; the caller max-reduces the pair and hands it to
+ * eae_adam_step_dp, which is eae_adam_step_scaled with those words as the refusal switches (NULL: the local switches).  eae_dp_init is time-bounded
+ * (EAE_DP_INIT_TIMEOUT_S, default 120 s; needs ncclCommInitRankConfig): a peer that never joins yields an error, not a hang. */
+int eae_dp_local_bad(eae_ctx* ctx, void* stream, unsigned* out_dev);
+int eae_adam_step_dp(eae_ctx* ctx, void* stream, float lr, float weight_decay, float grad_scale, const unsigned* peer_bad);
 /* Synchronized BatchNorm across data-parallel replicas (new work; SURVEY.md 8e: R ranks x B/R with SyncBN == 1 rank x B).
  * In train mode the engine calls `fn` once per BatchNorm layer in the forward (kind 0: `count` int64 fixed-point accumulators
  * starting at element `elem_offset` of acc_i64) and once per layer in the backward (kind 1: `count` fp64 sums at element

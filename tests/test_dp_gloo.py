@@ -108,34 +108,47 @@ def test_dp_world2_gloo(tmp_path):
 
 
 class _FakeLib:
-    """libeae stand-in for the communicator entry points: rank `fail_rank` cannot join (raises like a missing librccl symbol would)."""
+    """libeae stand-in for the communicator entry points.  `fail_at`: ("init", r) -- rank r cannot join (eae_dp_init fails like a refused
+    communicator would); ("unique_id", r) -- rank r cannot even reach the library (a missing librccl symbol); None -- every rank joins.
+    The all-reduce stand-in is a REAL collective (gloo all-reduce of the gradient words): a rank that entered it while a peer never
+    does would hang the test, which is exactly what the bring-up protocol has to exclude."""
 
-    def __init__(self, rank, fail_rank):
-        self.rank, self.fail_rank, self.destroyed = rank, fail_rank, False
+    def __init__(self, rank, fail_at, eng):
+        self.rank, self.fail_at, self.destroyed, self.eng, self.world_now, self.allreduces = rank, fail_at, False, eng, 0, 0
 
     def eae_dp_world(self, ctx):
-        return 0
+        return self.world_now
 
     def eae_dp_unique_id(self, buf):
+        if self.fail_at == ("unique_id", self.rank):
+            return -5
+        for i in range(128):
+            buf[i] = (i * 7 + 1) & 255
         return 0
 
     def eae_dp_init(self, ctx, rank, world, raw):
-        if rank == self.fail_rank:
+        assert bytes(raw) == bytes(((i * 7 + 1) & 255) for i in range(128)), "every rank must receive rank 0's id"
+        if self.fail_at == ("init", rank):
             return -5
+        self.world_now = world
         return 0
 
     def eae_dp_allreduce_bucket(self, ctx, stream, off, count):
+        self.allreduces += 1
+        lo, n = int(off.value), int(count.value)
+        dist.all_reduce(self.eng.grads[lo:lo + n], op=dist.ReduceOp.SUM)
         return 0
 
     def eae_dp_destroy(self, ctx):
         self.destroyed = True
+        self.world_now = 0
         return 0
 
     def eae_last_error(self):
-        return b"simulated: ncclCommInitRank failed"
+        return b"simulated: the communicator could not be brought up"
 
 
-def _worker_fallback(rank, world, port, tmp):
+def _worker_fallback(rank, world, port, tmp, fail_at):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -143,7 +156,7 @@ def _worker_fallback(rank, world, port, tmp):
         from eae_amd import dp, _lib
         eng = OracleEngine(seed=7)
         eng.ctx, eng.device = object(), torch.device("cpu")
-        eng.lib = _FakeLib(rank, fail_rank=1)
+        eng.lib = _FakeLib(rank, fail_at, eng)
         _lib.load = lambda: eng.lib                          # check() reads the error text through the loaded library
         real_backend = dist.get_backend
         dist.get_backend = lambda group=None: "nccl"         # take the native branch (the collectives underneath stay gloo)
@@ -151,21 +164,26 @@ def _worker_fallback(rank, world, port, tmp):
             tr = dp.DataParallelTrainer(eng, native=True)
         finally:
             dist.get_backend = real_backend
-        # rank 1 could not join; rank 0 could (its self-check fails later on the CPU stand-in anyway): BOTH must have left the native
-        # path, or the first collective of a half-native group would hang
-        assert tr.native is False and tr.rccl_ranks() == 0 and eng.lib.destroyed
         flags = [torch.zeros(1) for _ in range(world)]
-        dist.all_gather(flags, torch.tensor([0.0 if tr.native else 1.0]))
-        assert all(float(f) == 1.0 for f in flags)
-        # ... and the torch.distributed exchange works from there
-        import golden_util as gu
-        tr.broadcast_parameters(src=0)
-        x, y = gu.make_images(4, 901)
-        tr.train_step(torch.from_numpy(x[rank * 2:(rank + 1) * 2]), torch.from_numpy(y[rank * 2:(rank + 1) * 2]), 35.0, 1e-3)
-        mine = eng.params.clone()
-        other = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(other, mine)
-        assert torch.equal(other[0], other[1])
+        dist.all_gather(flags, torch.tensor([1.0 if tr.native else 0.0]))
+        if fail_at is None:
+            # every rank joined and the known-vector all-reduce came out right on every rank: the engine-owned exchange is trusted
+            assert tr.native is True and all(float(f) == 1.0 for f in flags) and eng.lib.allreduces == 1 and not eng.lib.destroyed
+            assert tr.rccl_ranks() == world
+        else:
+            # ONE rank failed: EVERY rank has left the native path (a half-native group would hang in its first collective), and no
+            # rank has entered the engine's all-reduce -- the good ranks would have waited there for ever
+            assert tr.native is False and tr.rccl_ranks() == 0 and eng.lib.destroyed and eng.lib.allreduces == 0
+            assert all(float(f) == 0.0 for f in flags)
+            # ... and the torch.distributed exchange works from there
+            import golden_util as gu
+            tr.broadcast_parameters(src=0)
+            x, y = gu.make_images(4, 901)
+            tr.train_step(torch.from_numpy(x[rank * 2:(rank + 1) * 2]), torch.from_numpy(y[rank * 2:(rank + 1) * 2]), 35.0, 1e-3)
+            mine = eng.params.clone()
+            other = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(other, mine)
+            assert torch.equal(other[0], other[1])
         if rank == 0:
             open(os.path.join(tmp, "ok"), "w").write("ok")
     finally:
@@ -173,12 +191,15 @@ def _worker_fallback(rank, world, port, tmp):
 
 
 @pytest.mark.timeout(600)
-def test_native_exchange_failure_on_one_rank_makes_every_rank_fall_back(tmp_path):
-    """dp.DataParallelTrainer joins the engine-owned RCCL communicator and proves it on a known vector; if ANY rank fails, ALL ranks
-    must take the torch.distributed path (agreed through one all-reduce of a flag).  Two gloo ranks, a libeae stand-in whose
-    eae_dp_init fails on rank 1 only."""
-    port = 31500 + (os.getpid() % 2000)
-    mp.spawn(_worker_fallback, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("fail_at", [("init", 1), ("init", 0), ("unique_id", 0), ("unique_id", 1), None],
+                         ids=["init-fails-on-rank1", "init-fails-on-rank0", "rank0-cannot-draw-an-id", "rank1-cannot-reach-rccl", "all-join"])
+def test_native_exchange_failure_on_one_rank_makes_every_rank_fall_back(tmp_path, fail_at):
+    """dp.DataParallelTrainer brings the engine-owned RCCL communicator up with the SAME sequence of collectives on every rank whatever
+    fails locally, and proves it on a known vector; if ANY rank fails at ANY stage, ALL ranks take the torch.distributed path and none
+    has entered the engine's all-reduce (the stand-in's is a real collective: entering it alone hangs the test).  Two gloo ranks."""
+    port = 31500 + (os.getpid() % 2000) + 7 * (["init1", "init0", "id0", "id1", "none"].index(
+        {("init", 1): "init1", ("init", 0): "init0", ("unique_id", 0): "id0", ("unique_id", 1): "id1", None: "none"}[fail_at]))
+    mp.spawn(_worker_fallback, args=(2, port, str(tmp_path), fail_at), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok")
 
 

@@ -52,6 +52,24 @@ def test_concurrent_grid_configs_are_bitwise_the_sequential_ones(tmp_path):
     assert all(torch.equal(sa[k], sb[k]) for k in sa)
 
 
+def test_concurrent_grid_with_the_default_fit_fn_is_seeded_like_the_sequential_one(tmp_path):
+    """The DEFAULT fit_fn under torch.manual_seed: the concurrent grid builds its models in grid order on the calling
+    thread, so every configuration starts from the parameters the sequential grid draws for it -- same validation losses bit for
+    bit, same winner, same saved weights (list loaders: no shuffling that would draw from the global generator)."""
+    from eae_amd import train as T
+    tr, va = _loaders()
+    kw = dict(alpha_values=(20, 35), lr_values=(1e-3, 5e-3), num_epochs=2, patience=15, verbose=False)
+    torch.manual_seed(4321)
+    seq = T.grid_search_autoencoder(tr, va, out_dir=str(tmp_path / "seq"), concurrent=1, **kw)
+    for k in (2, 4):
+        torch.manual_seed(4321)
+        con = T.grid_search_autoencoder(tr, va, out_dir=str(tmp_path / f"con{k}"), concurrent=k, **kw)
+        assert seq["results"] == con["results"], (k, seq["results"], con["results"])
+        assert (seq["best_alpha"], seq["best_lr"]) == (con["best_alpha"], con["best_lr"])
+        sa, sb = torch.load(seq["best_path"]), torch.load(con["best_path"])
+        assert all(torch.equal(sa[key], sb[key]) for key in sa)
+
+
 def test_concurrent_steps_from_threads_scale_and_stay_deterministic():
     """K engines stepped from K threads (train.run_concurrent): same parameters as the same steps issued from one thread."""
     import eae_amd

@@ -182,10 +182,46 @@ def gen_round3(ref):
     print(f"  ae_adam2_bn_b32.npz: {os.path.getsize(os.path.join(OUT, 'ae_adam2_bn_b32.npz')) / 1e6:.3f} MB")
 
 
+def gen_round4(ref):
+    """`python tools/make_golden.py --round4`: ae_nan_step_b8.npz -- what ONE step of the reference's loop (R.md:646-654) does to the
+    model when the batch holds a non-finite value (x[3, 1, 10, 10] = inf, the input of tests/test_gpu_ae.py's divergence tests): the
+    fraction of NaN entries of every parameter, of both Adam moments and of every BatchNorm buffer after the step, and the loss."""
+    SAE = ref["SupervisedAutoencoder"]
+    torch.manual_seed(gu.AE_SEED)
+    m = SAE(latent_dim=64, num_classes=10)
+    load_np(m, gu.perturb_bn(sd_np(m)))
+    m.train()
+    alpha, lr = 35.0, 5e-3
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    x, y = gu.make_images(8, 11)
+    x = x.copy()
+    x[3, 1, 10, 10] = np.inf
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    opt.zero_grad()
+    xh, lg, _ = m(xt)
+    loss = alpha * nn.MSELoss()(xh, xt) + nn.CrossEntropyLoss()(lg, yt)
+    loss.backward()
+    opt.step()
+    st = {"alpha": np.float32(alpha), "lr": np.float32(lr), "seed": np.int64(11), "loss": np.float32(loss.item())}
+    for k, v in m.state_dict().items():
+        if v.is_floating_point():
+            st[f"nan_frac/{k}"] = np.float32(torch.isnan(v).float().mean().item())
+    for n, p in m.named_parameters():
+        s_ = opt.state[p]
+        st[f"nan_frac_m/{n}"] = np.float32(torch.isnan(s_["exp_avg"]).float().mean().item())
+        st[f"nan_frac_v/{n}"] = np.float32(torch.isnan(s_["exp_avg_sq"]).float().mean().item())
+    np.savez_compressed(os.path.join(OUT, "ae_nan_step_b8.npz"), **st)
+    print("  ae_nan_step_b8.npz: loss", loss.item(), "param NaN fractions", sorted(set(float(v) for k, v in st.items() if k.startswith("nan_frac/") and "running" not in k)))
+    print("  BatchNorm buffers:", {k.split("/", 1)[1]: float(v) for k, v in st.items() if k.startswith("nan_frac/") and "running" in k})
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
+    if "--round4" in sys.argv:
+        gen_round4(ref)
+        return
     if "--round3" in sys.argv:
         gen_round3(ref)
         return
