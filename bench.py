@@ -338,7 +338,7 @@ def main():
             # ranks of the RCCL communicator the ENGINE owns (eae_dp_init): the driver's SCALE record can confirm that N ranks exchanged
             out["rccl_ranks"] = trainer.rccl_ranks()
             out["config"]["dp_exchange"] = ("engine-owned RCCL communicator, decoder-side bucket overlapped with the encoder backward"
-                                            if trainer.native and os.environ.get("EAE_DP_OVERLAP", "1") != "0" else
+                                            if trainer.native and os.environ.get("EAE_DP_OVERLAP", "0") == "1" else
                                             "engine-owned RCCL communicator, one all-reduce after the backward" if trainer.native else
                                             "torch.distributed all-reduce")
         # step-level roofline context

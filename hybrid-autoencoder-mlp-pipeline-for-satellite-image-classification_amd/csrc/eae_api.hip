@@ -680,7 +680,10 @@ unsigned* poison_word(const eae_ctx* c) { return reinterpret_cast<unsigned*>(c->
 int ensure_packed(eae_ctx* c, hipStream_t st) {
   if (c->packed) return 0;
   // (the pack kernel also clears the step-wide non-finite word: the optimizer kernel that clears the accumulators READS that word)
-  RC(eae_launch_pack_all(st, c->descs_dev, c->ndesc, c->P, c->pack, c->fp8 ? c->q : nullptr, poison_word(c)));
+  // (the four latent-projection packs are 96 % of the elements at 256x256 inputs -- 16.7 M each: four times the workgroups there)
+  static const int pack_blocks_big = getenv("EAE_PACK_BLOCKS") ? atoi(getenv("EAE_PACK_BLOCKS")) : 1024;
+  RC(eae_launch_pack_all(st, c->descs_dev, c->ndesc, c->P, c->pack, c->fp8 ? c->q : nullptr, poison_word(c),
+                         (long long)c->K * c->Lp >= (1LL << 22) ? pack_blocks_big : 256));
   c->packed = true;
   return 0;
 }

@@ -35,9 +35,12 @@ int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B
   a.sig = sig; a.sig_val = sig_val;
   a.src3 = src3; a.B = B; a.H = H; a.W = W; a.side = side; a.part = scratch;
   a.ntiles = eae_edge_tiles(B, H, W);
-  static const int cap = getenv("EAE_EDGE_WGRAD_BLOCKS") ? atoi(getenv("EAE_EDGE_WGRAD_BLOCKS")) : 1024;   // 4 blocks per CU fit: one round of workgroups (0.510-0.514 vs 0.514-0.517 ms per step with 512)
+  // Workgroups: each writes a partial, so their number also sets the reduction behind the kernel.  Round 4 re-sweep at B=512 (ms per
+  // step, main / side cap): 1024 / 1024 0.4875-0.4891, 512 / 1024 0.4832, 512 / 512 0.4821, 512 / 256 0.4794-0.4795, 768 / 256 0.4788,
+  // 512 / 128 0.4836, 640 / 192 0.4887, 256 main 0.4930.
+  static const int cap = getenv("EAE_EDGE_WGRAD_BLOCKS") ? atoi(getenv("EAE_EDGE_WGRAD_BLOCKS")) : 512;
   // a launch beside the backward-data chain (deconv4's weight gradient, side stream) takes fewer CUs from it with fewer blocks
-  static const int cap_side = getenv("EAE_EDGE_WGRAD_SIDE_BLOCKS") ? atoi(getenv("EAE_EDGE_WGRAD_SIDE_BLOCKS")) : 1024;
+  static const int cap_side = getenv("EAE_EDGE_WGRAD_SIDE_BLOCKS") ? atoi(getenv("EAE_EDGE_WGRAD_SIDE_BLOCKS")) : 256;
   const int lim = (src3_kind == SRC3_NHWC4_BF16) ? cap_side : cap;
   int nblocks = a.ntiles < lim ? a.ntiles : lim;
   while ((long long)nblocks * 864 > scratch_floats && nblocks > 1) nblocks /= 2;

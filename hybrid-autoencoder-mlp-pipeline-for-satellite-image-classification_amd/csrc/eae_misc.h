@@ -47,7 +47,9 @@ int eae_launch_bn_bwd_coef(hipStream_t st, const double* sums, int C, long long 
 struct GateArgs { unsigned* word[4]; unsigned want[4]; int n; unsigned* timeout; unsigned long long limit_ticks; };
 int eae_launch_gate(hipStream_t st, const GateArgs& g);
 int eae_launch_signal(hipStream_t st, unsigned* word, unsigned val);
-int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base, Fp8State* q = nullptr, unsigned* clear_word = nullptr);
+// blocks_per_desc: workgroups per descriptor (grid.x; every descriptor loops over its elements / tiles with that stride)
+int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base, Fp8State* q = nullptr, unsigned* clear_word = nullptr,
+                        int blocks_per_desc = 256);
 int eae_launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
                     double eps, double wd, long long step);
 int eae_launch_adam_dyn(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double b1, double b2, double eps,

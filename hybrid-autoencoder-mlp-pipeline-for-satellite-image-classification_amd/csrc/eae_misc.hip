@@ -312,24 +312,34 @@ __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc*
     // dec.fc's transposed layout dst[l][p*Cc + c] <- src[(c*P + p)][l]: 64 x 64 tiles through LDS (rows of the source are read whole,
     // rows of the destination are written in 128-byte pieces); element-per-thread gathers one float per source line and lane.
     // Only for the big shapes (>= 1024 tiles: 256x256 inputs): at 64x64 the 64 tiles are too few blocks (11.4 vs 8.9 us per step).
+    // (round 4: 16-byte loads and 16-byte stores -- a thread converts 8 consecutive destination elements -- instead of one float per
+    //  lane in and one bf16 per lane out: a 2-byte store costs ~12x a 16-byte one per byte, the kernel was store-instruction-bound)
     __shared__ float tile[64][65];
     const unsigned Lp = (unsigned)d.d0, Cc = (unsigned)d.d1, P = (unsigned)d.d2, lv = (unsigned)d.lv, J = Cc * P;
     const unsigned ncc = Cc / 64, nlc = Lp / 64, ntiles = P * ncc * nlc;
+    const bool vec = (lv & 3u) == 0;
     bf16_t* dst = reinterpret_cast<bf16_t*>(pack_base + d.dst_off);
     for (unsigned tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
       const unsigned lc = tl % nlc, cch = (tl / nlc) % ncc, p = tl / (nlc * ncc);
       const unsigned c0 = cch * 64, l0 = lc * 64;
       __syncthreads();
-#pragma unroll 4
-      for (unsigned k = 0; k < 16; ++k) {
-        const unsigned idx = threadIdx.x + 256u * k, l = idx & 63u, ci = idx >> 6;
-        tile[ci][l] = (l0 + l < lv) ? src[((size_t)(c0 + ci) * P + p) * lv + l0 + l] : 0.f;
+#pragma unroll
+      for (unsigned k = 0; k < 4; ++k) {         // 64 rows (ci) x 16 float4 (l)
+        const unsigned idx = threadIdx.x + 256u * k, l4 = (idx & 15u) * 4u, ci = idx >> 4;
+        const float* sp = src + ((size_t)(c0 + ci) * P + p) * lv + l0 + l4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec && l0 + l4 + 3 < lv) v = *reinterpret_cast<const float4*>(sp);
+        else { if (l0 + l4 < lv) v.x = sp[0]; if (l0 + l4 + 1 < lv) v.y = sp[1]; if (l0 + l4 + 2 < lv) v.z = sp[2]; if (l0 + l4 + 3 < lv) v.w = sp[3]; }
+        tile[ci][l4] = v.x; tile[ci][l4 + 1] = v.y; tile[ci][l4 + 2] = v.z; tile[ci][l4 + 3] = v.w;
       }
       __syncthreads();
-#pragma unroll 4
-      for (unsigned k = 0; k < 16; ++k) {
-        const unsigned idx = threadIdx.x + 256u * k, ci = idx & 63u, l = idx >> 6;
-        dst[(size_t)(l0 + l) * J + (size_t)p * Cc + c0 + ci] = (bf16_t)f2bf(tile[ci][l]);
+#pragma unroll
+      for (unsigned k = 0; k < 2; ++k) {         // 64 destination rows (l) x 8 pieces of 8 consecutive channels
+        const unsigned idx = threadIdx.x + 256u * k, c8 = (idx & 7u) * 8u, l = idx >> 3;
+        uint4 o;
+        o.x = pack2(tile[c8][l], tile[c8 + 1][l]); o.y = pack2(tile[c8 + 2][l], tile[c8 + 3][l]);
+        o.z = pack2(tile[c8 + 4][l], tile[c8 + 5][l]); o.w = pack2(tile[c8 + 6][l], tile[c8 + 7][l]);
+        *reinterpret_cast<uint4*>(dst + (size_t)(l0 + l) * J + (size_t)p * Cc + c0 + c8) = o;
       }
     }
     return;
@@ -350,19 +360,23 @@ __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc*
       const unsigned pc = tl % npc, ac = (tl / npc) % nA, fix = tl / (npc * nA);
       const unsigned p0 = pc * 64, a0 = ac * 64;                 // a = channel (row-major form) or row (transposed form)
       __syncthreads();
-#pragma unroll 4
-      for (unsigned k = 0; k < 16; ++k) {
-        const unsigned idx = threadIdx.x + 256u * k, pp = idx & 63u, ai = idx >> 6;
+#pragma unroll
+      for (unsigned k = 0; k < 4; ++k) {         // 64 rows (a) x 16 float4 along p (16-byte loads: see the transposed dec.fc form above)
+        const unsigned idx = threadIdx.x + 256u * k, p4 = (idx & 15u) * 4u, ai = idx >> 4;
         const unsigned r = rowmajor ? fix : a0 + ai, c = rowmajor ? a0 + ai : fix;
-        tile[ai][pp] = r < lv ? src[(size_t)r * K + (size_t)c * P + p0 + pp] : 0.f;
+        const float4 v = r < lv ? *reinterpret_cast<const float4*>(src + (size_t)r * K + (size_t)c * P + p0 + p4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        tile[ai][p4] = v.x; tile[ai][p4 + 1] = v.y; tile[ai][p4 + 2] = v.z; tile[ai][p4 + 3] = v.w;
       }
       __syncthreads();
-#pragma unroll 4
-      for (unsigned k = 0; k < 16; ++k) {
-        const unsigned idx = threadIdx.x + 256u * k, ai = idx & 63u, pp = idx >> 6;
-        const size_t o = rowmajor ? (size_t)fix * K + (size_t)(p0 + pp) * Cc + a0 + ai
-                                  : ((size_t)(p0 + pp) * Cc + fix) * R + a0 + ai;
-        dst[o] = (bf16_t)f2bf(tile[ai][pp]);
+#pragma unroll
+      for (unsigned k = 0; k < 2; ++k) {         // 64 destination rows (p) x 8 pieces of 8 consecutive a
+        const unsigned idx = threadIdx.x + 256u * k, a8 = (idx & 7u) * 8u, pp = idx >> 3;
+        uint4 o;
+        o.x = pack2(tile[a8][pp], tile[a8 + 1][pp]); o.y = pack2(tile[a8 + 2][pp], tile[a8 + 3][pp]);
+        o.z = pack2(tile[a8 + 4][pp], tile[a8 + 5][pp]); o.w = pack2(tile[a8 + 6][pp], tile[a8 + 7][pp]);
+        const size_t oo = rowmajor ? (size_t)fix * K + (size_t)(p0 + pp) * Cc + a0 + a8
+                                   : ((size_t)(p0 + pp) * Cc + fix) * R + a0 + a8;
+        *reinterpret_cast<uint4*>(dst + oo) = o;
       }
     }
     return;
@@ -390,6 +404,23 @@ __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc*
     }
     return;
   }
+  if (d.mode == PACK_FC_ROWPERM && !d.out_f32 && (d.lv & 7) == 0 && (d.d0 & 7) == 0) {
+    // dec.fc's row-permuted layout dst[p*Cc + c][l] <- src[c*P + p][l]: whole rows move, so a thread takes 8 consecutive l (two 16-byte
+    // loads, one 16-byte store) instead of one float in and one bf16 out (16.7 M elements at 256x256 inputs)
+    const unsigned Lp = (unsigned)d.d0, Cc = (unsigned)d.d1, P = (unsigned)d.d2, lv = (unsigned)d.lv, n8 = count / 8u, l8n = Lp / 8u;
+    bf16_t* dst = reinterpret_cast<bf16_t*>(pack_base + d.dst_off);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n8; i += gridDim.x * 256u) {
+      const unsigned l = (i % l8n) * 8u, j2 = i / l8n, cc = j2 % Cc, pp = j2 / Cc;
+      uint4 o = make_uint4(0, 0, 0, 0);
+      if (l < lv) {
+        const float4* sp = reinterpret_cast<const float4*>(src + (size_t)(cc * P + pp) * lv + l);
+        const float4 a = sp[0], b = sp[1];
+        o.x = pack2(a.x, a.y); o.y = pack2(a.z, a.w); o.z = pack2(b.x, b.y); o.w = pack2(b.z, b.w);
+      }
+      *reinterpret_cast<uint4*>(dst + (size_t)i * 8u) = o;
+    }
+    return;
+  }
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
     float v = pack_fetch(d, src, i);
     if (d.out_f32) reinterpret_cast<float*>(pack_base + d.dst_off)[i] = v;
@@ -397,8 +428,9 @@ __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc*
   }
 }
 
-int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base, Fp8State* q, unsigned* clear_word) {
-  hipLaunchKernelGGL(pack_all_kernel, dim3(256, ndesc), dim3(256), 0, st, descs_dev, params, (uint8_t*)pack_base, q, clear_word);
+int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base, Fp8State* q, unsigned* clear_word,
+                        int blocks_per_desc) {
+  hipLaunchKernelGGL(pack_all_kernel, dim3(blocks_per_desc > 0 ? blocks_per_desc : 256, ndesc), dim3(256), 0, st, descs_dev, params, (uint8_t*)pack_base, q, clear_word);
   EAE_LAUNCH_CHECK();
   return 0;
 }
