@@ -153,6 +153,17 @@ struct eae_ctx {
   // plain tensor, or does the weight gradient transform g and y itself and run BESIDE the backward-data kernel?  bit i (1..3) =
   // enc.conv(i+1), bit 4 + i (0..2) = dec.deconv(i+1).  EAE_DY_MASK overrides (diagnostic A/B).
   unsigned dy_mask = 0;
+  // Split optimizer of the fused eager step (round 4): Adam + pack of gradient tensors 8..37 run on a side stream as soon as those
+  // tensors are complete, beside conv2's backward-data and conv1's weight gradient; only tensors 0..7 (conv1, conv2 and their
+  // BatchNorms) are updated and packed behind the join.  ndesc_late = leading pack descriptors that read tensors 0..7.
+  int ndesc_late = 0;
+  // Default OFF (measured, B=512, same box): one optimizer launch behind the join 0.4743 ms; split with full-width bulk kernels
+  // 0.4837; bulk narrowed to 256 / 128 / 64 workgroups 0.4833 / 0.4905 / 0.5128.  The timeline (gpurun_out/r4tl3) shows why: both side
+  // streams are busy with the last weight gradients until the main chain ends (that is what the 64-workgroup grids balance), so the
+  // bulk starts behind conv3's weight gradient and the join waits for it -- the work is conserved, it only moves.
+  bool split_opt = false;          // EAE_SPLIT_OPT=1 switches it on
+  bool bulk_done = false;          // backward_impl has enqueued the bulk part of this step's optimizer
+  unsigned bulk_seq = 0;
   int nan_exact = 0;               // EAE_NAN_EXACT=1: a diverged step writes NaN into every parameter and moment like the reference's does
   bool skip_wgrad = false;         // EAE_SKIP_WGRAD=1 (diagnostic): the six 3x3 weight gradients are not launched (main chain alone)
   bool use_gates = true;           // device-side gates instead of event records on the caller's stream (EAE_FORK_EVENTS=1: events)
@@ -317,6 +328,9 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   }
   c->pk_bd = pcarve(c->K * 4); add(c->poff[19], c->pk_bd, c->K, PACK_FC_ROWPERM, 1, 256, (int)c->Pn, 1);
   c->ndesc = (int)descs.size();
+  c->ndesc_late = 0;
+  while (c->ndesc_late < c->ndesc && descs[c->ndesc_late].src_off < c->poff[8]) c->ndesc_late++;
+  for (int k = c->ndesc_late; k < c->ndesc; ++k) if (descs[k].src_off < c->poff[8]) c->ndesc_late = -1;      // (not a prefix: no split)
   size_t o_pack = carve(poffb), o_desc = carve(descs.size() * sizeof(PackDesc)), o_q = carve(sizeof(Fp8State)), o_bns = carve(2048 * 4 + 64);
   hipError_t e = hipMalloc(&c->ws, off);
   if (e != hipSuccess) { delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
@@ -374,6 +388,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   // layers' backward-data kernels are built without the store (eae_igemm.hip.h: DY), so bits 1 and 6 are never honoured.
   c->dy_mask = (getenv("EAE_DY_MASK") ? (unsigned)strtoul(getenv("EAE_DY_MASK"), nullptr, 0) : 0u) & 0x3cu;
   c->skip_wgrad = getenv("EAE_SKIP_WGRAD") != nullptr;
+  c->split_opt = getenv("EAE_SPLIT_OPT") && atoi(getenv("EAE_SPLIT_OPT")) != 0;
   c->nan_exact = (getenv("EAE_NAN_EXACT") && atoi(getenv("EAE_NAN_EXACT")) != 0) ? 1 : 0;
   c->fold_fwd = getenv("EAE_NO_FOLD_FWD") == nullptr;
   c->fold_bwd = getenv("EAE_NO_FOLD_BWD") == nullptr;
@@ -997,8 +1012,11 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
 }
 
 // part 0 = everything, 1 = classifier + decoder + dec.fc (gradient tensors 18..37), 2 = enc.fc + encoder (tensors 0..17)
-int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float* dz_ext = nullptr, int part = 0) {
+// fused_lr != nullptr: the caller is the fused eager train step and will run the optimizer for tensors 0..7 behind this call; the bulk
+// of the optimizer (tensors 8..37) is enqueued HERE on a side stream when the context allows it (c->bulk_done tells the caller)
+int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float* dz_ext = nullptr, int part = 0, const float* fused_lr = nullptr) {
   const int B = io->B, H = c->H, W = c->W;
+  c->bulk_done = false;
   // (part 2 = the encoder half: behind part 1 of a split backward -- whose side-stream consumers may still be reading the decoder
   //  layers' sums -- nothing is cleared; the stand-alone encoder backward clears before it calls)
   if (part != 2) RC(prep_bwd_accumulators(c, st));
@@ -1176,6 +1194,17 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     const int cs = ENC_C[i + 1], cb = ENC_C[i];       // conv weight [cs][cb][3][3]
     const int Hs = H >> (i + 1), Ws = W >> (i + 1);   // output (small) map of the conv
     const bool dym = (c->dy_mask >> i) & 1u;         // (see the transposed layers above)
+    // conv2 (the last hand-over of the step) with a split optimizer: its weight gradient is pinned to side stream 0, the bulk of the
+    // optimizer to side stream 1, both released when conv2's backward-data kernel starts (= conv3's has finished: every gradient
+    // tensor >= 8 the main chain writes is complete); a signal in FRONT of the weight gradient tells the bulk that side stream 0's
+    // earlier members are done too.  Everything is joined behind conv1's weight gradient as before.
+    const bool split = i == 1 && fused_lr != nullptr && part == 0 && !dp && c->split_opt && c->use_side && gates_now(c) && c->nx >= 1 &&
+                       !c->fp8 && !c->skip_wgrad && !dym && c->ndesc_late > 0 && c->M && c->V;
+    if (split) {
+      c->bulk_seq += 1;
+      RC(eae_launch_signal(side_stream(c, 0), c->sigwords + 10, c->bulk_seq));
+      c->side_used |= 1u;
+    }
     auto push_wgrad = [&]() {
       if (c->skip_wgrad) return;
       sq_push(c, [=](hipStream_t s2, float* scr) {
@@ -1187,8 +1216,27 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
         if (c->fp8) w.qs = c->q->qs_wg[i - 1];
         return eae_launch_wgrad_s2(s2, w, cs, cb, dym ? SRC_RAWG : SRC_BNBWD, SRC_BNRELU, scr, c->wscratch_floats, c->G + c->poff[4 * i],
                                    prof_hook_for(c, EAE_PROF_SITE(i, 2)));
-      });
+      }, split ? 0 : -1);
       sq_fork(c);              // released by the next kernel of the chain (dy mode, conv2: by conv1's weight gradient)
+      if (split) {
+        const float lr = *fused_lr;
+        const unsigned seq = c->bulk_seq;
+        sq_push(c, [=](hipStream_t s1, float*) {
+          GateArgs g = GateArgs();
+          g.word[0] = c->sigwords + 10; g.want[0] = seq; g.n = 1; g.timeout = c->sigwords + 8; g.limit_ticks = c->gate_limit;
+          RC(eae_launch_gate(s1, g));
+          const long long o8 = c->poff[8];
+          // (few workgroups: the two kernels have ~60 us of slack beside conv2's backward-data and conv1's weight gradient, which are the
+          //  critical chain -- at full width they took bandwidth and CUs from it and the step got 1 % SLOWER than with one optimizer launch)
+          static const int ab = getenv("EAE_BULK_ADAM_BLOCKS") ? atoi(getenv("EAE_BULK_ADAM_BLOCKS")) : 128;
+          static const int pb = getenv("EAE_BULK_PACK_BLOCKS") ? atoi(getenv("EAE_BULK_PACK_BLOCKS")) : 32;
+          const bool big = (long long)c->K * c->Lp >= (1LL << 22);
+          RC(eae_launch_adam_scaled(s1, c->P + o8, c->G + o8, c->M + o8, c->V + o8, c->poff[38] - o8, lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f,
+                                    nullptr, 0, c->sigwords + 8, poison_word(c), c->last_loss, c->nan_exact, big ? 2048 : ab));
+          return eae_launch_pack_all(s1, c->descs_dev + c->ndesc_late, c->ndesc - c->ndesc_late, c->P, c->pack, nullptr, nullptr, big ? 1024 : pb);
+        }, 1);
+        c->bulk_done = true;
+      }
     };
     if (!dym) push_wgrad();
     ConvArgs a = ConvArgs();
@@ -1406,14 +1454,24 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
   }
   if (!ent) {      // plain eager step: Adam takes its bias-correction scalars by value (one launch less on the critical path)
     int rc = forward_impl(c, st, io, true);
-    if (!rc) rc = backward_impl(c, st, io);
-    if (!rc) {
-      c->adam_step += 1;             // (behind the launches that can fail: a failed step must not advance the bias correction)
+    c->adam_step += 1;               // (the bulk optimizer inside backward_impl needs this step's count; taken back when the step fails)
+    if (!rc) rc = backward_impl(c, st, io, nullptr, 0, &lr);
+    bool packed = false;
+    if (!rc && c->bulk_done) {
+      // tensors 8..37 were updated and packed on a side stream beside the end of the backward (joined by now): the rest behind the join
+      const long long n8 = c->poff[8];
+      rc = eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, n8, lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f,
+                                  c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss, c->nan_exact);
+      if (!rc) rc = eae_launch_pack_all(st, c->descs_dev, c->ndesc_late, c->P, c->pack, nullptr, poison_word(c), 64);
+      packed = rc == 0;
+    } else if (!rc) {
       rc = eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f,
                                   c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss, c->nan_exact);
     }
+    if (rc) c->adam_step -= 1;
+    c->bulk_done = false;
     c->last_loss = nullptr;
-    c->packed = false; c->acc_clean = (rc == 0); c->bwd_dirty = !c->acc_clean;
+    c->packed = packed; c->acc_clean = (rc == 0); c->bwd_dirty = !c->acc_clean;
     return rc;
   }
   c->adam_step += 1;

@@ -57,6 +57,7 @@ int eae_launch_adam_dyn(hipStream_t st, float* p, const float* g, float* m, floa
 int eae_launch_set_dyn(hipStream_t st, float* dyn, double lr, double b1, double b2, double wd, long long step);
 int eae_launch_adam_scaled(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
                            double eps, double wd, long long step, float gscale, void* zero_buf = nullptr, long long zero_bytes = 0,
-                           const unsigned* bad = nullptr, const unsigned* bad2 = nullptr, float* nan_out = nullptr, int nan_fill = 0);
+                           const unsigned* bad = nullptr, const unsigned* bad2 = nullptr, float* nan_out = nullptr, int nan_fill = 0,
+                           int max_blocks = 0 /* 0: 2048; the grid-stride loop covers the rest */);
 int eae_launch_augment(hipStream_t st, const void* in_u8, float* out, int B, int H, int W, int train, float std, unsigned long long seed,
                        unsigned long long step, const int* params, const float* noise);

@@ -600,12 +600,13 @@ int eae_launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v
 
 int eae_launch_adam_scaled(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
                            double eps, double wd, long long step, float gscale, void* zero_buf, long long zero_bytes,
-                           const unsigned* bad, const unsigned* bad2, float* nan_out, int nan_fill) {
+                           const unsigned* bad, const unsigned* bad2, float* nan_out, int nan_fill, int max_blocks) {
   if (n % 4) return eae_set_error(-2, "adam: arena length must be a multiple of 4");
   double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
   long n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  if (max_blocks <= 0) max_blocks = 2048;
+  if (blocks > max_blocks) blocks = max_blocks;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4, (float)b1, (float)b2, (float)(lr / bc1),
                      (float)sqrt(bc2), (float)eps, (float)wd, gscale, (uint4*)zero_buf, (long)(zero_bytes / 16), bad, bad2, nan_out, nan_fill);
   EAE_LAUNCH_CHECK();

@@ -439,6 +439,28 @@ def test_determinism():
     assert np.array_equal(outs[0], outs[1])
 
 
+def test_split_optimizer_is_bitwise_the_single_launch_one(monkeypatch):
+    """EAE_SPLIT_OPT=1 (round 4, off by default: measured slower): Adam + pack of gradient tensors 8..37 on a side stream beside the end
+    of the backward, tensors 0..7 behind the join.  The same elementwise update on the same gradients: parameters, moments, BatchNorm
+    buffers and the next step's forward (i.e. the packs) are bitwise those of the single optimizer launch."""
+    x, y = gu.make_images(48, 100)
+    xd, yd = _cuda(x), _cuda(y)
+    outs = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("EAE_SPLIT_OPT", split)
+        m = _model()
+        eng = _engine(m, max_batch=48)
+        for s in range(3):
+            eng.train_step(xd, yd, 35.0, 5e-3)
+        torch.cuda.synchronize()
+        assert eng.gate_timeouts() == 0
+        xh, lg, z = eng.forward(xd, labels=yd, train=False, alpha=35.0)
+        torch.cuda.synchronize()
+        outs.append((eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.bn_running.clone(), xh.clone(), z.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_data_parallel_trainer_world1_rccl():
     """The DP step (grad_step -> bucketed all-reduce over RCCL -> adam_step) on a 1-rank NCCL group equals the fused
     single-GPU train_step bit for bit (the multi-rank arithmetic is covered on CPU by tests/test_dp_gloo.py)."""
