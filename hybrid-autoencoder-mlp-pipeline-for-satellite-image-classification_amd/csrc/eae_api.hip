@@ -12,6 +12,8 @@
 #include <cstring>
 #include <cstdlib>
 #include <chrono>
+#include <future>
+#include <memory>
 #include <thread>
 
 static thread_local std::string g_err;
@@ -1604,12 +1606,9 @@ struct RcclApi {
   decltype(&ncclAllReduce) allReduce = nullptr;
   decltype(&ncclBroadcast) broadcast = nullptr;
   decltype(&ncclGetErrorString) getErrorString = nullptr;
-  // optional (older libraries lack them): grouped launches, time-bounded communicator bring-up
+  // optional (older libraries lack them): grouped launches
   decltype(&ncclGroupStart) groupStart = nullptr;
   decltype(&ncclGroupEnd) groupEnd = nullptr;
-  decltype(&ncclCommInitRankConfig) commInitRankConfig = nullptr;
-  decltype(&ncclCommGetAsyncError) commGetAsyncError = nullptr;
-  decltype(&ncclCommAbort) commAbort = nullptr;
   std::string err;
 };
 RcclApi* rccl_api() {
@@ -1629,9 +1628,6 @@ RcclApi* rccl_api() {
     if (!a.getUniqueId || !a.commInitRank || !a.commDestroy || !a.allReduce || !a.broadcast || !a.getErrorString) a.err = "librccl lacks a required symbol";
     a.groupStart = reinterpret_cast<decltype(a.groupStart)>(dlsym(a.h, "ncclGroupStart"));
     a.groupEnd = reinterpret_cast<decltype(a.groupEnd)>(dlsym(a.h, "ncclGroupEnd"));
-    a.commInitRankConfig = reinterpret_cast<decltype(a.commInitRankConfig)>(dlsym(a.h, "ncclCommInitRankConfig"));
-    a.commGetAsyncError = reinterpret_cast<decltype(a.commGetAsyncError)>(dlsym(a.h, "ncclCommGetAsyncError"));
-    a.commAbort = reinterpret_cast<decltype(a.commAbort)>(dlsym(a.h, "ncclCommAbort"));
     return a;
   }();
   return &api;
@@ -1661,28 +1657,29 @@ extern "C" int eae_dp_init(eae_ctx* c, int rank, int world, const void* id128) {
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   ncclComm_t comm = nullptr;
-  // Time-bounded bring-up (EAE_DP_INIT_TIMEOUT_S, default 120; 0 = blocking call): ncclCommInitRank is a rendezvous of all ranks and
-  // blocks for ever when a peer never arrives.  With the non-blocking configuration the call returns at once and the communicator is
-  // polled until it is ready, fails, or the time is up -- then it is aborted and the caller falls back (dp.py: every rank together).
+  // Time-bounded bring-up (EAE_DP_INIT_TIMEOUT_S, default 120; 0 = plain blocking call): ncclCommInitRank is a rendezvous of all ranks
+  // and blocks for ever when a peer never arrives.  It runs on a helper thread and the caller waits for it with a deadline; on a
+  // time-out the call returns an error (dp.py: every rank falls back together) and the helper is left behind, still blocked.
+  // (Not ncclCommInitRankConfig(blocking = 0): that makes EVERY later call on the communicator non-blocking -- an all-reduce may then
+  //  return ncclInProgress and has to be polled -- which the enqueue-only train step does not want.)
   static const double limit_s = getenv("EAE_DP_INIT_TIMEOUT_S") ? atof(getenv("EAE_DP_INIT_TIMEOUT_S")) : 120.0;
-  if (limit_s > 0 && r->commInitRankConfig && r->commGetAsyncError) {
-    ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
-    cfg.blocking = 0;
-    ncclResult_t e = r->commInitRankConfig(&comm, world, id, rank, &cfg);
-    if (e != ncclSuccess && e != ncclInProgress) return rccl_fail(r, e, "ncclCommInitRankConfig");
-    const auto t0 = std::chrono::steady_clock::now();
-    ncclResult_t st_ = ncclInProgress;
-    while (true) {
-      e = r->commGetAsyncError(comm, &st_);
-      if (e != ncclSuccess) { if (r->commAbort) r->commAbort(comm); return rccl_fail(r, e, "ncclCommGetAsyncError"); }
-      if (st_ != ncclInProgress) break;
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
-        if (r->commAbort) r->commAbort(comm);
-        return eae_set_error(EAE_ERR_STATE, "dp_init: the communicator did not come up within EAE_DP_INIT_TIMEOUT_S (a peer never joined?)");
-      }
-      std::this_thread::sleep_for(std::chrono::milliseconds(2));
-    }
-    if (st_ != ncclSuccess) { if (r->commAbort) r->commAbort(comm); return rccl_fail(r, st_, "ncclCommInitRankConfig (asynchronous)"); }
+  if (limit_s > 0) {
+    int dev = 0;
+    EAE_HIP(hipGetDevice(&dev));
+    struct Box { std::promise<ncclResult_t> done; ncclComm_t comm = nullptr; };
+    auto box = std::make_shared<Box>();
+    std::future<ncclResult_t> fut = box->done.get_future();
+    auto fn = r->commInitRank;
+    std::thread([box, fn, world, id, rank, dev]() {
+      ncclResult_t e = ncclSystemError;
+      if (hipSetDevice(dev) == hipSuccess) e = fn(&box->comm, world, id, rank);
+      box->done.set_value(e);
+    }).detach();
+    if (fut.wait_for(std::chrono::duration<double>(limit_s)) != std::future_status::ready)
+      return eae_set_error(EAE_ERR_STATE, "dp_init: the communicator did not come up within EAE_DP_INIT_TIMEOUT_S (a peer never joined?)");
+    const ncclResult_t e = fut.get();
+    if (e != ncclSuccess) return rccl_fail(r, e, "ncclCommInitRank");
+    comm = box->comm;
   } else {
     RCCL(r->commInitRank(&comm, world, id, rank), "ncclCommInitRank");
   }

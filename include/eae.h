@@ -170,7 +170,8 @@ int eae_ae_dp_train_step(eae_ctx* ctx, void* stream, const eae_step_io* io, floa
  * the ranks next to the last gradient bucket.  For an exchange the caller runs itself (torch.distributed): eae_dp_local_bad writes this
  * rank's TWO flags (stale, diverged; 0 / 1 each) to a pair of device words on `stream`; the caller max-reduces the pair and hands it to
  * eae_adam_step_dp, which is eae_adam_step_scaled with those words as the refusal switches (NULL: the local switches).  eae_dp_init is time-bounded
- * (EAE_DP_INIT_TIMEOUT_S, default 120 s; needs ncclCommInitRankConfig): a peer that never joins yields an error, not a hang. */
+ * (EAE_DP_INIT_TIMEOUT_S, default 120 s: the rendezvous runs on a helper thread the caller waits for with a deadline; the communicator
+ * stays a BLOCKING one): a peer that never joins yields an error, not a hang. */
 int eae_dp_local_bad(eae_ctx* ctx, void* stream, unsigned* out_dev);
 int eae_adam_step_dp(eae_ctx* ctx, void* stream, float lr, float weight_decay, float grad_scale, const unsigned* peer_bad);
 /* Synchronized BatchNorm across data-parallel replicas (new work; SURVEY.md 8e: R ranks x B/R with SyncBN == 1 rank x B).

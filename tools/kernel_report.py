@@ -64,11 +64,14 @@ def table(rnd, tag):
     desc, B, hw, L = WL[tag]
     rows = {r["Name"]: r for r in csv.DictReader(open(stats))}
     pmc = json.load(open(pmc_path))["kernels"] if os.path.exists(pmc_path) else {}
+    # stand-alone durations per launch site (tools/kbench_sites.py; the fp8 workload shows its bf16 twins' numbers)
+    sa_path = os.path.join(ROOT, "profiles", f"{rnd}_standalone_{'c5bf16' if tag == 'c5fp8' else tag}.json")
+    alone = {int(k): v for k, v in json.load(open(sa_path))["us"].items()} if os.path.exists(sa_path) else {}
     work = {n: r for n, r in rows.items() if "gate_kernel" not in n}
     tot = sum(float(r["TotalDurationNs"]) for r in work.values())
     print(f"\n## {desc}\n\n`{os.path.relpath(stats, ROOT)}`" + (f" + `{os.path.relpath(pmc_path, ROOT)}`" if pmc else "") + "\n")
-    print("| kernel | role | calls | µs | % of kernel time | alg MB | GB/s | HBM frac | TFLOP/s | MFMA frac | PMC MB | PMC/alg | MFMA busy |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    print("| kernel | role | calls | µs in the step | µs alone | % of kernel time | alg MB | GB/s | HBM frac | HBM frac alone | TFLOP/s | MFMA frac | PMC MB | PMC/alg | MFMA busy |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     lines = []
     for n, r in work.items():
         us = float(r["AverageNs"]) / 1e3
@@ -90,12 +93,15 @@ def table(rnd, tag):
         k = pmc.get(n, {})
         tr, mu = k.get("traffic_bytes"), k.get("mfma_util")
         short = n.split("(")[0].replace("void ", "")
+        al = alone.get(site) if site is not None else None
+        als = f"{al:.1f}" if al is not None else "–"
         if byts is None:
-            lines.append((pct, f"| `{short}` | {role} | {r['Calls']} | {us:.1f} | {pct:.1f} | – | – | – | – | – | {tr / 1e6 if tr else float('nan'):.1f} | – | – |"))
+            lines.append((pct, f"| `{short}` | {role} | {r['Calls']} | {us:.1f} | {als} | {pct:.1f} | – | – | – | – | – | – | {tr / 1e6 if tr else float('nan'):.1f} | – | – |"))
             continue
         gbs = byts / (us * 1e-6) / 1e9
         tf = fl * 1e6 / (us * 1e-6) / 1e12
-        lines.append((pct, f"| `{short}` | {role.split(' (')[0]} | {r['Calls']} | {us:.1f} | {pct:.1f} | {byts / 1e6:.1f} | {gbs:.0f} | {gbs / HBM:.2f} | {tf:.0f} | "
+        fa = f"{byts / (al * 1e-6) / 1e9 / HBM:.2f}" if al else "–"
+        lines.append((pct, f"| `{short}` | {role.split(' (')[0]} | {r['Calls']} | {us:.1f} | {als} | {pct:.1f} | {byts / 1e6:.1f} | {gbs:.0f} | {gbs / HBM:.2f} | {fa} | {tf:.0f} | "
                            f"{tf / MFMA:.3f} | {tr / 1e6 if tr else float('nan'):.1f} | {tr / byts if tr else float('nan'):.2f} | "
                            f"{mu if mu is not None else float('nan'):.3f} |"))
     for _, l in sorted(lines, key=lambda t: -t[0]):
@@ -130,7 +136,10 @@ def main():
           "(SURVEY §8d model), `HBM frac` = alg bytes / time / 8 TB/s, `MFMA frac` = FLOPs / time / 2.5 PFLOP/s (bf16 dense peak, also for "
           "the fp8 kernels' rows), `PMC MB` = (2·FETCH_SIZE + WRITE_SIZE) per launch, `MFMA busy` = SQ_VALU_MFMA_BUSY_CYCLES / "
           "(GRBM_GUI_ACTIVE/8 · 1024 SIMDs): the fraction of the kernel's lifetime in which a SIMD's matrix pipe was busy, averaged over "
-          "all SIMDs (separate `--pmc` pass). `% of kernel time` excludes `gate_kernel`.")
+          "all SIMDs (separate `--pmc` pass). `% of kernel time` excludes `gate_kernel`. `µs alone` = the same launch site through the "
+          "per-op C ABI, back to back on an otherwise idle GPU (`tools/kbench_sites.py`; weight-gradient rows include their slice-reduction "
+          "launch, so they can exceed the in-step kernel alone; the fp8 table shows its bf16 twins): the gap to `µs in the step` is "
+          "contention -- side streams beside the backward-data chain -- not kernel quality.")
     for tag in ("b512", "c2", "c5fp8", "c5bf16"):
         table(rnd, tag)
 

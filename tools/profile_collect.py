@@ -52,6 +52,11 @@ def main():
         run = open(os.path.join(d, "run.txt")).read().strip() if os.path.exists(os.path.join(d, "run.txt")) else ""
         meta["workloads"][wl] = {"kernel_stats": os.path.relpath(dst, ROOT), "batch": BATCH[wl], "run": run,
                                  "command": f"rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --no-cpu-baseline --no-roofline --no-configs"}
+        sa = os.path.join(ROOT, "gpurun_out", f"prof_{rnd}", f"standalone_{tag}.json")      # tools/kbench_sites.py
+        if os.path.exists(sa):
+            sdst = os.path.join(ROOT, "profiles", f"{rnd}_standalone_{tag}.json")
+            shutil.copy(sa, sdst)
+            meta["workloads"][wl]["standalone"] = os.path.relpath(sdst, ROOT)
         fp = one(os.path.join(d, "FETCH_SIZE", "**", "*counter_collection.csv"))
         wp = one(os.path.join(d, "WRITE_SIZE", "**", "*counter_collection.csv"))
         mp = one(os.path.join(d, "MFMA", "**", "*counter_collection.csv"))
