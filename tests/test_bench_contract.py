@@ -16,7 +16,7 @@ def test_dominant_kernel_selection_matches_the_committed_summary():
     as rocprofv3 names it; gate rows (one waiting wave) are never picked; the profile carries the commit it was taken at."""
     from eae_amd import profile_hooks as ph
     stats = ph.newest_stats("b512")
-    assert stats and os.path.basename(stats).startswith(("r02_", "r03_")), stats
+    assert stats and os.path.basename(stats).startswith(("r02_", "r03_", "r04_")), stats
     name, row, skipped = ph.pick_dominant(stats)
     rows = {r["Name"]: r for r in csv.DictReader(open(stats))}
     assert name in rows and ph.site_of(name) is not None and "gate_kernel" not in name
@@ -67,7 +67,7 @@ def test_site_of_and_site_model_on_every_kernel_name_of_the_committed_summaries(
     for s in ph.all_sites():
         assert ph.site_model(s, 256, 256)[1] == 16 * ph.site_model(s, 64, 64)[1]
     assert len(ph.all_sites()) == 23
-    for f in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r03_bench_*_kernel_stats.csv"))):
+    for f in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r0[34]_bench_*_kernel_stats.csv"))):
         for r in csv.DictReader(open(f)):
             if any(k in r["Name"] for k in ("igemm", "wgrad_s2", "wgrad8", "edge_", "deconv4_loss")):
                 assert ph.site_of(r["Name"]) is not None, (f, r["Name"])
@@ -93,7 +93,7 @@ def test_bench_line_contract_and_roofline_arithmetic():
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9) <= 0.01 * rf["achieved"]
     assert abs(rf["avg_launch_us"] - (rf["event_bracket_us"] - rf["empty_bracket_us"])) < 0.05
     prof = rf["from_committed_profile"]
-    assert prof["summary"].startswith(("profiles/r02_", "profiles/r03_")) and rf["traffic"] == prof["pmc_traffic_bytes_per_launch"]
+    assert prof["summary"].startswith(("profiles/r02_", "profiles/r03_", "profiles/r04_")) and rf["traffic"] == prof["pmc_traffic_bytes_per_launch"]
     assert prof["summary_commit"]
     # the live duration and the committed rocprofv3 average of the same kernel agree (tracing changes how the streams line up)
     assert 0.6 <= rf["avg_launch_us"] / prof["rocprof_avg_us"] <= 1.4, (rf["avg_launch_us"], prof["rocprof_avg_us"])
@@ -117,5 +117,5 @@ def test_bench_side_workload_line_carries_its_own_roofline():
     role, bpi, mf = ph.site_model(rf["site"], 64, 64)
     assert rf["algorithmic_bytes_per_launch"] == 256 * bpi and ph.site_of(rf["kernel"]) == rf["site"]
     prof = rf["from_committed_profile"]
-    assert prof["summary"].startswith("profiles/r03_bench_c2_") and prof["summary_commit"]
+    assert prof["summary"].startswith(("profiles/r03_bench_c2_", "profiles/r04_bench_c2_")) and prof["summary_commit"]
     assert rf["traffic"] == prof["pmc_traffic_bytes_per_launch"]
