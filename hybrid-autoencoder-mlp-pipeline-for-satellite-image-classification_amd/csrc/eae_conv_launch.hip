@@ -2,6 +2,9 @@
 #include "eae_internal.h"
 #include "eae_igemm.hip.h"
 #include "eae_igemm2.hip.h"
+#ifdef EAE_IGEMM_MT       // multi-tile variant of the 16-wide geometries: built, parity-green, measured SLOWER -- A/B builds only
+#include "eae_igemm_mt.hip.h"
+#endif
 #include <cstdlib>
 
 namespace {
@@ -21,6 +24,39 @@ int launch(const ConvArgs& a, hipStream_t st) {   // NOLINT
   EAE_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef EAE_IGEMM_MT
+// Workgroups of a multi-tile launch (eae_igemm_mt.hip.h) with `nvb` (tile, channel block) pairs: at most EAE_IG_WGS_PER_CU (default 2)
+// x 256 CUs, a multiple of 8 * NB (all tiles of a workgroup then share its XCD run and its channel block), with equal shares where
+// the tile count allows.
+static int ig_mt_grid(int nvb, int nb) {
+  static const int per_cu = getenv("EAE_IG_WGS_PER_CU") ? atoi(getenv("EAE_IG_WGS_PER_CU")) : 2;
+  const int cap = (per_cu > 0 ? per_cu : 2) * 256, q = 8 * nb;
+  if (nvb <= cap || nvb % q != 0) return nvb;
+  for (int t = (nvb + cap - 1) / cap; t <= 256; ++t)
+    if (nvb % t == 0 && (nvb / t) % q == 0) return nvb / t;
+  return cap / q * q > 0 ? cap / q * q : q;
+}
+// EAE_IG_MT=0: one tile per workgroup for the 16-wide geometries too (rounds 1-3; A/B switch)
+static bool ig_mt_on() { static const bool v = !(getenv("EAE_IG_MT") && atoi(getenv("EAE_IG_MT")) == 0); return v; }
+// EAE_IG_MT_TH4=1: the 32 <-> 64-channel layers on 16 x 4-position tiles (twice the tiles per workgroup: a longer pipeline at B=512)
+static bool ig_mt_th4() { static const bool v = getenv("EAE_IG_MT_TH4") && atoi(getenv("EAE_IG_MT_TH4")) != 0; return v; }
+
+template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int SRC, int EPI>
+int launch_mt(const ConvArgs& a, hipStream_t st) {   // NOLINT
+  void (*kern)(ConvArgs) = igemm_mt_kernel<KIND, CIN, COUT, BN, TW, TH, SRC, EPI>;
+  if (a.qs) kern = igemm8_mt_kernel<KIND, CIN, COUT, BN, TW, TH, SRC, EPI>;
+  constexpr size_t smem = igemm_mt_smem<KIND, BN, TW, TH>();
+  EAE_HIP(eae_smem_attr(reinterpret_cast<const void*>(kern), smem));
+  const int Hpos = (KIND == KIND_CONV) ? a.Hin / 2 : a.Hin, Wpos = (KIND == KIND_CONV) ? a.Win / 2 : a.Win;
+  const int ntiles = a.B * (Hpos / TH) * (Wpos / TW);
+  ConvArgs b = a;
+  b.ntiles = ntiles;
+  hipLaunchKernelGGL(kern, dim3(ig_mt_grid(ntiles * (COUT / BN), COUT / BN)), dim3(256), smem, st, b);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+#endif
 
 // fp8 variant (BASELINE config 5): same geometry, operands converted to fp8 (ConvArgs::qs set by the engine); 16-wide tiles only
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
@@ -85,8 +121,13 @@ static bool deconv_small(int B, int Win, int cout) {
 template <int CIN, int COUT, int BN, int SRC, int EPI>
 int conv_geo(const ConvArgs& a, hipStream_t st) {
   const int Hp = a.Hin / 2, Wp = a.Win / 2;
-  if (Wp % 16 == 0 && Hp % 8 == 0)
+  if (Wp % 16 == 0 && Hp % 8 == 0) {
+#ifdef EAE_IGEMM_MT
+    if constexpr (CIN == 32) { if (ig_mt_on() && ig_mt_th4()) return launch_mt<KIND_CONV, CIN, COUT, BN, 16, 4, SRC, EPI>(a, st); }
+    if (ig_mt_on()) return launch_mt<KIND_CONV, CIN, COUT, BN, 16, 8, SRC, EPI>(a, st);
+#endif
     return a.qs ? launch8<KIND_CONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st) : launch<KIND_CONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st);
+  }
   if (a.qs) return eae_set_error(-2, "conv_s2: the fp8 variant needs output maps that are multiples of 8 x 16");
   if constexpr (CIN >= 64) {
     constexpr int NBL = (CIN == 64) ? COUT / BN : 1;       // two chunks: both stay resident, the workgroup loops over the channel blocks
@@ -114,8 +155,13 @@ int deconv_geo(const ConvArgs& a, hipStream_t st) {
   if constexpr (CIN == 64) {
     if (a.Win % 16 == 0 && a.Hin % 4 == 0 && deconv64_th4()) return launch<KIND_DECONV, CIN, COUT, BN, 16, 4, 1, SRC, EPI>(a, st);
   }
-  if (a.Win % 16 == 0 && a.Hin % 8 == 0)
+  if (a.Win % 16 == 0 && a.Hin % 8 == 0) {
+#ifdef EAE_IGEMM_MT
+    if constexpr (CIN == 64) { if (ig_mt_on() && ig_mt_th4()) return launch_mt<KIND_DECONV, CIN, COUT, BN, 16, 4, SRC, EPI>(a, st); }
+    if (ig_mt_on()) return launch_mt<KIND_DECONV, CIN, COUT, BN, 16, 8, SRC, EPI>(a, st);
+#endif
     return a.qs ? launch8<KIND_DECONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st) : launch<KIND_DECONV, CIN, COUT, BN, 16, 8, 1, SRC, EPI>(a, st);
+  }
   if (a.qs) return eae_set_error(-2, "deconv_s2: the fp8 variant needs input maps that are multiples of 8 x 16");
   if constexpr (CIN >= 128) {
     if (igemm2_on<KIND_DECONV, CIN, EPI>()) {
@@ -174,6 +220,10 @@ int eae_launch_deconv_s2(const ConvArgs& a, int cin, int cout, int src, int epi,
 // number of per-workgroup statistics partials (= grid.x) for a given shape
 int eae_conv_s2_ntiles(int kind, int B, int Hin, int Win, int cin) {
   if (kind == 1 && cin == 64 && Win % 16 == 0 && Hin % 4 == 0 && deconv64_th4()) return B * (Hin / 4) * (Win / 16);
+#ifdef EAE_IGEMM_MT
+  if (kind == 1 && cin == 64 && Win % 16 == 0 && Hin % 8 == 0 && ig_mt_on() && ig_mt_th4()) return B * (Hin / 4) * (Win / 16);
+  if (kind == 0 && cin == 32 && (Win / 2) % 16 == 0 && (Hin / 2) % 8 == 0 && ig_mt_on() && ig_mt_th4()) return B * (Hin / 8) * (Win / 32);
+#endif
   if (kind == 0) {
     int Hp = Hin / 2, Wp = Win / 2;
     if (Wp % 16 == 0 && Hp % 8 == 0) return B * (Hp / 8) * (Wp / 16);
