@@ -666,23 +666,33 @@ int fold_side2(eae_ctx* c) {
 }
 // join: work enqueued on `st` from now on starts after everything enqueued so far on the side streams.  With gates: every side
 // stream that received work publishes a done-counter with a one-thread kernel, ONE gate on `st` waits for all of them.
-int join_side(eae_ctx* c, hipStream_t st) {
-  if (!c->use_side) return 0;
+// join_side_begin: first half of the gated join -- commits the pending side groups, publishes the side streams' done-counters and
+// returns the gate that waits for them in *g (g->n == 0: nothing to wait for, or the event path is in use and join_side must follow).
+// A caller that has one more kernel to enqueue on `st` hands the gate to that kernel's tail instead of paying a launch for it.
+int join_side_begin(eae_ctx* c, hipStream_t st, GateArgs* g) {
+  *g = GateArgs();
+  if (!c->use_side || !gates_now(c)) return 0;
   RC(sq_commit(c, st));
   const int ns = 1 + c->nx;
+  g->timeout = c->sigwords + 8; g->limit_ticks = c->gate_limit;
+  for (int k = 0; k < ns; ++k) {
+    if (!(c->side_used & (1u << k))) continue;
+    c->side_done_seq[k] += 1;
+    RC(eae_launch_signal(side_stream(c, k), c->sigwords + 1 + k, c->side_done_seq[k]));
+    g->word[g->n] = c->sigwords + 1 + k; g->want[g->n] = c->side_done_seq[k]; g->n++;
+  }
+  c->side_used = 0;
+  return 0;
+}
+int join_side(eae_ctx* c, hipStream_t st) {
+  if (!c->use_side) return 0;
   if (gates_now(c)) {
-    GateArgs g = GateArgs();
-    g.timeout = c->sigwords + 8; g.limit_ticks = c->gate_limit;
-    for (int k = 0; k < ns; ++k) {
-      if (!(c->side_used & (1u << k))) continue;
-      c->side_done_seq[k] += 1;
-      RC(eae_launch_signal(side_stream(c, k), c->sigwords + 1 + k, c->side_done_seq[k]));
-      g.word[g.n] = c->sigwords + 1 + k; g.want[g.n] = c->side_done_seq[k]; g.n++;
-    }
+    GateArgs g;
+    RC(join_side_begin(c, st, &g));
     if (g.n) RC(eae_launch_gate(st, g));
-    c->side_used = 0;
     return 0;
   }
+  RC(sq_commit(c, st));
   EAE_HIP(hipEventRecord(c->ev_join, c->side));
   EAE_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
   for (int i = 0; i < c->nx; ++i) {
@@ -1272,10 +1282,16 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
   {
     ConvArgs sg = ConvArgs();                          // carries the progress value that releases conv2's weight gradient
     take_sig(c, sg);
+    // the join with the side streams rides in the tail of this weight gradient's slice reduction (one launch less in the step's
+    // tail).  The side groups are committed BETWEEN the two launches: gates go behind the kernel that releases them (see sq_commit).
+    static const bool tail_gate = !getenv("EAE_TAIL_GATE") || atoi(getenv("EAE_TAIL_GATE")) != 0;
+    struct Mid { eae_ctx* c; hipStream_t st; } mid = {c, st};
+    auto mid_fn = [](void* u, GateArgs* g) { Mid* m = static_cast<Mid*>(u); return join_side_begin(m->c, m->st, g); };
     RC(eae_launch_edge_wgrad(st, SRC3_NCHW_F32, io->x, B, H, W, src_bnbwd(c->gy[0], c->y[0], c->coef_b[0]), SRC_BNBWD, c->wscratch_main,
-                             2048LL * 864, c->G + c->poff[0], prof_hook_for(c, EAE_PROF_CONV1_WGRAD), &bf0, sg.sig, sg.sig_val));
+                             2048LL * 864, c->G + c->poff[0], prof_hook_for(c, EAE_PROF_CONV1_WGRAD), &bf0, sg.sig, sg.sig_val,
+                             tail_gate ? +mid_fn : nullptr, &mid));
   }
-  RC(join_side(c, st));
+  RC(join_side(c, st));                                 // (nothing left to wait for when the gate went with the reduction)
   if (c->fp8) RC(eae_launch_fp8_scales(st, c->q));      // every reader of this step's scales has finished: derive the next step's
   // Biases in front of a BatchNorm have an identically zero gradient (the reference computes ~1e-9 rounding noise);
   // their slots in the gradient arena are zeroed once in eae_bind and never written.

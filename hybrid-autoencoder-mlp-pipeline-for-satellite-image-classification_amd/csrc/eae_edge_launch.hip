@@ -28,8 +28,10 @@ int eae_edge_tiles(int B, int H, int W) { return B * (H / 2 / E_TH) * (W / 2 / E
 // dw [32][3][3][3] = reduce over blocks of the per-block partials. scratch must hold nblocks*864 floats.
 int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B, int H, int W, const SrcDesc& side, int smode,
                           float* scratch, long long scratch_floats, float* dw, const EaeProfHook* hook, const BnBwdFold* bfold,
-                          unsigned* sig, unsigned sig_val) {
+                          unsigned* sig, unsigned sig_val, int (*mid)(void*, GateArgs*), void* mid_user) {
   if (int rc = check_edge_shape(B, H, W)) return rc;
+  // the kernel addresses both operands through buffer descriptors with 32-bit byte offsets below OOB_OFF
+  if ((long long)B * H * W * 16 >= 0x7fffff00LL) return eae_set_error(-2, "edge_wgrad: batch too large for one launch (2 GB per operand)");
   EdgeWgradArgs a;
   a.bfold = bfold ? *bfold : BnBwdFold();
   a.sig = sig; a.sig_val = sig_val;
@@ -54,7 +56,9 @@ int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B
 #undef CASE
   return eae_set_error(-2, "edge_wgrad: combination not instantiated");
 reduce:
-  hipLaunchKernelGGL(reduce_slices_tall_kernel, dim3((864 / 4 + 3) / 4), dim3(256), 0, st, scratch, nblocks, (long)(864 / 4), dw);
+  GateArgs tail = GateArgs();      // mid(): the caller's work between the two launches; a gate it returns is waited for in the reduction's tail
+  if (mid) { if (int rc = mid(mid_user, &tail)) return rc; }
+  hipLaunchKernelGGL(reduce_slices_tall_kernel, dim3((864 / 4 + 3) / 4), dim3(256), 0, st, scratch, nblocks, (long)(864 / 4), dw, tail);
   EAE_LAUNCH_CHECK();
   return 0;
 }

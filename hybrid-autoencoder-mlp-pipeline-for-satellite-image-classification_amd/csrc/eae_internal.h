@@ -38,7 +38,8 @@ int eae_launch_edge_conv(hipStream_t st, int src3_kind, int epi, const EdgeArgs&
 int eae_edge_tiles(int B, int H, int W);
 int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B, int H, int W, const SrcDesc& side, int smode,
                           float* scratch, long long scratch_floats, float* dw, const EaeProfHook* hook = nullptr,
-                          const struct BnBwdFold* bfold = nullptr, unsigned* sig = nullptr, unsigned sig_val = 0);
+                          const struct BnBwdFold* bfold = nullptr, unsigned* sig = nullptr, unsigned sig_val = 0,
+                          int (*mid)(void*, GateArgs*) = nullptr, void* mid_user = nullptr);
 int eae_launch_deconv4_loss(hipStream_t st, int smode, const Deconv4Args& a);
 int eae_launch_wgrad_s2(hipStream_t st, const WgradArgs& a, int cs, int cb, int smode, int bmode, float* scratch,
                         long long scratch_floats, float* dw, const EaeProfHook* hook = nullptr);

@@ -46,6 +46,20 @@ int eae_launch_bn_bwd_coef(hipStream_t st, const double* sums, int C, long long 
 // gate gave up waiting for (the optimizer kernels refuse to update while it is set, eae_gate_timeouts())
 struct GateArgs { unsigned* word[4]; unsigned want[4]; int n; unsigned* timeout; unsigned long long limit_ticks; };
 int eae_launch_gate(hipStream_t st, const GateArgs& g);
+// the wait itself (ONE lane calls it): gate_kernel's body, also run in the tail of conv1's weight-gradient reduction
+__device__ __forceinline__ void gate_wait(const GateArgs& g) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int k = 0; k < g.n; ++k) {
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(g.word[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.want[k]) < 0) {
+      __builtin_amdgcn_s_sleep(16);
+      if ((++spins & 255u) == 0 && g.limit_ticks != 0 && __builtin_amdgcn_s_memrealtime() - t0 > g.limit_ticks) {
+        atomicExch(g.timeout, g.want[k] ? g.want[k] : 1u);
+        return;
+      }
+    }
+  }
+}
 int eae_launch_signal(hipStream_t st, unsigned* word, unsigned val);
 // blocks_per_desc: workgroups per descriptor (grid.x; every descriptor loops over its elements / tiles with that stride)
 int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base, Fp8State* q = nullptr, unsigned* clear_word = nullptr,

@@ -171,18 +171,7 @@ int eae_launch_bn_bwd_finalize(hipStream_t st, const float* part, int ntiles, in
 // kernel to carry it.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ EAE_NO_PK __launch_bounds__(64) void gate_kernel(GateArgs g) {
-  if (threadIdx.x != 0) return;
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  for (int k = 0; k < g.n; ++k) {
-    unsigned spins = 0;
-    while ((int)(__hip_atomic_load(g.word[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.want[k]) < 0) {
-      __builtin_amdgcn_s_sleep(16);
-      if ((++spins & 255u) == 0 && g.limit_ticks != 0 && __builtin_amdgcn_s_memrealtime() - t0 > g.limit_ticks) {
-        atomicExch(g.timeout, g.want[k] ? g.want[k] : 1u);
-        return;
-      }
-    }
-  }
+  if (threadIdx.x == 0) gate_wait(g);
 }
 __global__ EAE_NO_PK void signal_kernel(unsigned* word, unsigned val) {
   if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -364,8 +364,10 @@ static inline unsigned reduce_slices_grid(long n4) { return (unsigned)((n4 + 15)
 
 // Tall variant for few outputs and many slices (conv1 / deconv4 weight gradients: 216 float4, 512 slices): 4 float4 columns
 // x 64 slice lanes per block -> 4x the blocks and a quarter of the serial loads per thread; fixed summation order.
+// tail: an optional gate (eae_misc.h GateArgs, same protocol as gate_kernel) that block 0 waits for AFTER its share of the reduction,
+// so the kernels behind this one on the stream also follow the signalling streams' work.
 static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_tall_kernel(const float* __restrict__ part, int nslices, long n4,
-                                                                                float* __restrict__ out) {
+                                                                                float* __restrict__ out, GateArgs tail) {
   __shared__ float4 red[64][4];
   const int lx = threadIdx.x & 3, ly = threadIdx.x >> 2;
   const long i = (long)blockIdx.x * 4 + lx;
@@ -388,4 +390,5 @@ static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_tall_kerne
     for (int k = 1; k < 64; ++k) { r.x += red[k][lx].x; r.y += red[k][lx].y; r.z += red[k][lx].z; r.w += red[k][lx].w; }
     reinterpret_cast<float4*>(out)[i] = r;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && tail.n) gate_wait(tail);
 }
