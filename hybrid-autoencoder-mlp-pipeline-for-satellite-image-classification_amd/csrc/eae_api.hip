@@ -25,6 +25,13 @@ extern "C" int eae_version(void) { return 100; }
 // release at the end of every kernel is what makes its results visible to the other streams' kernels)
 static const unsigned EV_FLAGS = hipEventDisableTiming | (getenv("EAE_EVENT_SYSTEM_FENCE") ? 0u : hipEventDisableSystemFence);
 
+thread_local GroupRec* eae_rec = nullptr;        // eae_group.h
+thread_local int eae_geo_mult = 1;
+int eae_rec_fail(const char* what) {
+  if (eae_rec && !eae_rec->error) eae_rec->error = EAE_ERR_STATE;
+  return eae_set_error(EAE_ERR_STATE, what);
+}
+
 namespace {
 
 constexpr float BN_EPS = 1e-5f, BN_MOM = 0.1f;
@@ -775,7 +782,7 @@ void fold_consumer(eae_ctx* c, BnFold& f, int l, long long count, bool train) {
 // as a side job, any other sequence (forward only, external optimizer, encoder / decoder alone) pays one memset here
 int prep_accumulators(eae_ctx* c, hipStream_t st, bool train) {
   if (!train || !c->fold_fwd) return 0;
-  if (!c->acc_clean || c->capturing) { EAE_HIP(hipMemsetAsync(c->acc_base, 0, c->acc_bytes, st)); c->bwd_dirty = false; }   // a captured step always carries it
+  if (!c->acc_clean || c->capturing) { EAE_HIP(eae_memset_async(c->acc_base, 0, c->acc_bytes, st)); c->bwd_dirty = false; }   // a captured step always carries it
   c->acc_clean = false;
   return 0;
 }
@@ -785,7 +792,7 @@ int prep_accumulators(eae_ctx* c, hipStream_t st, bool train) {
 // used to pile up (found by the EAE_NO_FOLD_FWD x fp8-calibration sweep: 8 gradient steps, gradients 92x too large)
 int prep_bwd_accumulators(eae_ctx* c, hipStream_t st) {
   if (!c->fold_bwd) return 0;
-  if (c->bwd_dirty) EAE_HIP(hipMemsetAsync(c->acc_base + c->acc_half, 0, c->poison_off - c->acc_half, st));
+  if (c->bwd_dirty) EAE_HIP(eae_memset_async(c->acc_base + c->acc_half, 0, c->poison_off - c->acc_half, st));
   c->bwd_dirty = true; c->acc_clean = false;
   return 0;
 }
@@ -894,7 +901,7 @@ int run_encoder(eae_ctx* c, hipStream_t st, const float* x, int B, bool train) {
   f.a = src_bnrelu(c->y[3], c->coef_f[3]);
   f.w = (const bf16_t*)(c->pack + c->pk_we1);
   f.M = B; f.N = c->Lp; f.K = (int)c->K; f.klen = fc_klen(c); f.part = c->fcpart;
-  fold_consumer(c, f.fold, 3, (long long)B * c->Pn, train);
+  fold_consumer(c, f.c.fold, 3, (long long)B * c->Pn, train);
   const int ksplit = (int)(c->K / f.klen);
   RC(eae_launch_fc_nt(st, f, SRC_BNRELU, FCE_PARTIAL, ksplit));
   RC(eae_launch_fc_reduce(st, c->fcpart, ksplit, B, c->Lp, c->lpad ? (const float*)(c->pack + c->pk_bep) : c->P + c->poff[17], nullptr,
@@ -992,7 +999,7 @@ int forward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, bool want_gr
       float* logits = io->logits;
       sq_push(c, [=](hipStream_t hs, float*) {
         RC(run_head(c, hs, B, labels, logits, true, nullptr));
-        EAE_HIP(hipEventRecord(c->ev_head, hs));
+        EAE_HIP(eae_event_record(c->ev_head, hs));
         return 0;
       }, 0);
       sq_fork(c);                  // released by the decoder's first kernel (run_decoder commits behind it)
@@ -1034,7 +1041,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
   if (part != 2) RC(prep_bwd_accumulators(c, st));
   if (c->prebn_dirty && !c->bwd_eval) {      // train mode again: those biases have an identically zero gradient, never written
     for (int k = 0; k < 7; ++k)
-      EAE_HIP(hipMemsetAsync(c->G + c->poff[PREBN_BIAS[k]], 0, (size_t)(c->poff[PREBN_BIAS[k] + 1] - c->poff[PREBN_BIAS[k]]) * 4, st));
+      EAE_HIP(eae_memset_async(c->G + c->poff[PREBN_BIAS[k]], 0, (size_t)(c->poff[PREBN_BIAS[k] + 1] - c->poff[PREBN_BIAS[k]]) * 4, st));
     c->prebn_dirty = false;
   }
   const bool head = io->head != 0;
@@ -1052,10 +1059,10 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     if (head) {
       sq_push(c, [=](hipStream_t ss, float*) {
         const int nb = eae_head_blocks(B, c->Lp);
-        hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(c->head_stride / 4)), dim3(256), 0, ss, c->headpart, nb,
-                           (long)(c->head_stride / 4), c->lpad ? c->gs_head : c->G + c->poff[34], 1.0f);
+        launch_reduce_slices(ss, c->headpart, nb, (long)(c->head_stride / 4), c->lpad ? c->gs_head : c->G + c->poff[34], 1.0f);
         EAE_LAUNCH_CHECK();
         if (c->lpad) {     // padded shadow -> arena: classifier.0.weight [128][L], then bias / classifier.2 (contiguous)
+          EAE_NO_GROUP("a latent width that needs the padded classifier shadow");
           EAE_HIP(hipMemcpy2DAsync(c->G + c->poff[34], (size_t)c->L * 4, c->gs_head, (size_t)c->Lp * 4, (size_t)c->L * 4, 128,
                                    hipMemcpyDeviceToDevice, ss));
           EAE_HIP(hipMemcpyAsync(c->G + c->poff[35], c->gs_head + 128LL * c->Lp, (size_t)(c->poff[38] - c->poff[35]) * 4,
@@ -1065,7 +1072,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
       }, 0);
     } else {
       sq_push(c, [=](hipStream_t ss, float*) {
-        EAE_HIP(hipMemsetAsync(c->G + c->poff[34], 0, (size_t)(c->poff[38] - c->poff[34]) * 4, ss));
+        EAE_HIP(eae_memset_async(c->G + c->poff[34], 0, (size_t)(c->poff[38] - c->poff[34]) * 4, ss));
         return 0;
       }, 0);
     }
@@ -1161,7 +1168,7 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
       const int ksplit = (int)(c->K / f.klen);
       RC(eae_launch_fc_nt(st, f, SRC_RAW, FCE_PARTIAL, ksplit));
       if (c->sq_forked) RC(sq_commit(c, st));
-      if (c->head_pending) { EAE_HIP(hipStreamWaitEvent(st, c->ev_head, 0)); c->head_pending = false; }
+      if (c->head_pending) { EAE_HIP(eae_stream_wait_event(st, c->ev_head)); c->head_pending = false; }
       int src_rc = 0;
       const float* dze = stage_latent_in(c, st, dz_ext, B, &src_rc);      // caller's [B][L] gradient -> padded rows
       RC(src_rc);
@@ -1182,8 +1189,8 @@ int backward_impl(eae_ctx* c, hipStream_t st, const eae_step_io* io, const float
     t.out = c->lpad ? c->gs_encw : c->G + c->poff[16]; t.colsum = c->lpad ? c->gs_encb : c->G + c->poff[17]; t.out_mode = 1; t.Pn = (int)c->Pn;
     RC(eae_launch_fc_tn(s2, t, SRC_F32, SRC_BNRELU));
     if (c->lpad) {       // the first L rows of the padded shadows are the arena tensors
-      EAE_HIP(hipMemcpyAsync(c->G + c->poff[16], c->gs_encw, (size_t)c->L * c->K * 4, hipMemcpyDeviceToDevice, s2));
-      EAE_HIP(hipMemcpyAsync(c->G + c->poff[17], c->gs_encb, (size_t)c->L * 4, hipMemcpyDeviceToDevice, s2));
+      EAE_HIP(eae_memcpy_d2d_async(c->G + c->poff[16], c->gs_encw, (size_t)c->L * c->K * 4, s2));
+      EAE_HIP(eae_memcpy_d2d_async(c->G + c->poff[17], c->gs_encb, (size_t)c->L * 4, s2));
     }
     return 0;
   });
@@ -1446,6 +1453,30 @@ extern "C" int eae_adam_step_scaled(eae_ctx* c, void* stream, float lr, float we
   return 0;
 }
 
+// The plain eager step: Adam takes its bias-correction scalars by value (one launch less on the critical path).
+static int train_step_eager(eae_ctx* c, hipStream_t st, const eae_step_io* io, float lr) {
+  int rc = forward_impl(c, st, io, true);
+  c->adam_step += 1;               // (the bulk optimizer inside backward_impl needs this step's count; taken back when the step fails)
+  if (!rc) rc = backward_impl(c, st, io, nullptr, 0, &lr);
+  bool packed = false;
+  if (!rc && c->bulk_done) {
+    // tensors 8..37 were updated and packed on a side stream beside the end of the backward (joined by now): the rest behind the join
+    const long long n8 = c->poff[8];
+    rc = eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, n8, lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f,
+                                c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss, c->nan_exact);
+    if (!rc) rc = eae_launch_pack_all(st, c->descs_dev, c->ndesc_late, c->P, c->pack, nullptr, poison_word(c), 64);
+    packed = rc == 0;
+  } else if (!rc) {
+    rc = eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f,
+                                c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss, c->nan_exact);
+  }
+  if (rc) c->adam_step -= 1;
+  c->bulk_done = false;
+  c->last_loss = nullptr;
+  c->packed = packed; c->acc_clean = (rc == 0); c->bwd_dirty = !c->acc_clean;
+  return rc;
+}
+
 // One iteration of the batch loop.  Steady state (same buffers, batch size and alpha as the previous calls, parameters
 // last touched by this engine's own Adam): the whole step -- pack, forward, loss, backward on two streams, Adam -- is replayed
 // from a captured hipGraph; the only per-step host work is one tiny launch that refreshes Adam's bias-correction scalars.
@@ -1470,28 +1501,7 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
     if (!ent && c->ngraphs < eae_ctx::NGRAPH) { ent = &c->graphs[c->ngraphs++]; ent->key = key; }
     if (ent) ent->seen++;
   }
-  if (!ent) {      // plain eager step: Adam takes its bias-correction scalars by value (one launch less on the critical path)
-    int rc = forward_impl(c, st, io, true);
-    c->adam_step += 1;               // (the bulk optimizer inside backward_impl needs this step's count; taken back when the step fails)
-    if (!rc) rc = backward_impl(c, st, io, nullptr, 0, &lr);
-    bool packed = false;
-    if (!rc && c->bulk_done) {
-      // tensors 8..37 were updated and packed on a side stream beside the end of the backward (joined by now): the rest behind the join
-      const long long n8 = c->poff[8];
-      rc = eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, n8, lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f,
-                                  c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss, c->nan_exact);
-      if (!rc) rc = eae_launch_pack_all(st, c->descs_dev, c->ndesc_late, c->P, c->pack, nullptr, poison_word(c), 64);
-      packed = rc == 0;
-    } else if (!rc) {
-      rc = eae_launch_adam_scaled(st, c->P, c->G, c->M, c->V, c->poff[38], lr, 0.9, 0.999, 1e-8, 0.0, c->adam_step, 1.0f,
-                                  c->acc_base, (long long)c->poison_off, c->sigwords + 8, poison_word(c), c->last_loss, c->nan_exact);
-    }
-    if (rc) c->adam_step -= 1;
-    c->bulk_done = false;
-    c->last_loss = nullptr;
-    c->packed = packed; c->acc_clean = (rc == 0); c->bwd_dirty = !c->acc_clean;
-    return rc;
-  }
+  if (!ent) return train_step_eager(c, st, io, lr);
   c->adam_step += 1;
   RC(eae_launch_set_dyn(st, c->dyn, lr, 0.9, 0.999, 0.0, c->adam_step));
   if (ent && ent->exec) {
@@ -1518,6 +1528,110 @@ extern "C" int eae_ae_train_step(eae_ctx* c, void* stream, const eae_step_io* io
     EAE_HIP(hipGraphLaunch(ent->exec, st));
   }
   return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Grouped train step (eae_group.h): K contexts of one shape -- the grid of (alpha, lr) configurations the reference trains one
+// after the other at batch 64 (R.md:599-711) -- stepped by ONE sequence of launches.  Every member's step logic runs with the recorder
+// installed (its own state advances exactly as in eae_ae_train_step's eager path), the K recordings are zipped and enqueued on the
+// FIRST member's streams.  The members must agree in everything that shapes the launches (configuration, batch size, which
+// outputs are requested); what they need not share: parameters, statistics, inputs, labels, alpha, lr.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+int group_slot_of(void* ctx, hipStream_t user, hipStream_t st) {
+  eae_ctx* c = static_cast<eae_ctx*>(ctx);
+  if (st == user) return 0;
+  if (st == c->side) return 1;
+  for (int i = 0; i < c->nx; ++i) if (st == c->sidex[i]) return 2 + i;
+  return -1;
+}
+hipStream_t group_stream(eae_ctx* c, hipStream_t user, int slot) { return slot == 0 ? user : slot == 1 ? c->side : c->sidex[slot - 2]; }
+
+}  // namespace
+
+extern "C" int eae_set_geometry_mult(int mult) {
+  if (mult < 1 || mult > 64) return eae_set_error(EAE_ERR_ARG, "geometry_mult: 1..64");
+  eae_geo_mult = mult;
+  return 0;
+}
+
+extern "C" int eae_group_train_step(eae_ctx* const* ctxs, int n, void* stream, const eae_step_io* ios, const float* lrs) {
+  if (!ctxs || !ios || !lrs || n < 1 || n > 64) return eae_set_error(EAE_ERR_ARG, "group_train_step: 1..64 contexts, one io block and one lr each");
+  if (eae_rec) return eae_set_error(EAE_ERR_STATE, "group_train_step: already recording on this thread");
+  hipStream_t user = (hipStream_t)stream;
+  eae_ctx* c0 = ctxs[0];
+  for (int k = 0; k < n; ++k) {
+    eae_ctx* c = ctxs[k];
+    RC(check_io(c, &ios[k], true));
+    if (!c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: moment arenas must be bound");
+    if (c->prof_on || c->fp8 || c->dp_comm || !c->use_gates || c->use_side != c0->use_side || c->nx != c0->nx)
+      return eae_set_error(EAE_ERR_STATE, "group_train_step: members must share device and stream layout, with profiling, fp8 and data parallel off");
+    for (int j = 0; j < k; ++j) if (ctxs[j] == c) return eae_set_error(EAE_ERR_ARG, "group_train_step: a context appears twice");
+  }
+  static thread_local std::vector<GroupRec> recs;
+  if ((int)recs.size() < n) recs.resize(n);
+  static const bool timing = getenv("EAE_GROUP_TIMING") != nullptr;      // diagnostic: host microseconds of the three phases, every 100th call
+  static thread_local double t_acc[3] = {0, 0, 0};
+  static thread_local int t_n = 0;
+  const auto tp0 = std::chrono::steady_clock::now();
+  // (recording a member costs ~3 us of host time -- the step logic without its launches; a thread pool that recorded the members side
+  //  by side was measured slower than this loop: waking a worker costs more than the work it takes)
+  const int mult0 = eae_geo_mult;
+  eae_geo_mult = n;
+  for (int k = 0; k < n; ++k) {
+    GroupRec& r = recs[k];
+    r.clear();
+    r.ctx = ctxs[k]; r.user = user; r.slot_of = &group_slot_of;
+    eae_rec = &r;
+    const int rc = train_step_eager(ctxs[k], user, &ios[k], lrs[k]);
+    eae_rec = nullptr;
+    if (rc && !r.error) r.error = rc;
+    if (r.error) r.msg = eae_last_error();
+  }
+  eae_geo_mult = mult0;
+  // (on a failure the members have advanced their host-side state all the same: the group is unusable, as a context is after a failed step)
+  for (int k = 0; k < n; ++k) if (recs[k].error) return eae_set_error(recs[k].error, recs[k].msg.c_str());
+  const auto tp1 = std::chrono::steady_clock::now();
+  // zip
+  const size_t len = recs[0].items.size();
+  for (int k = 1; k < n; ++k) {
+    if (recs[k].items.size() != len) return eae_set_error(EAE_ERR_STATE, "group_train_step: the members' steps differ in length (different shapes or state)");
+    for (size_t i = 0; i < len; ++i) {
+      const GroupItem& a = recs[0].items[i];
+      const GroupItem& b = recs[k].items[i];
+      if (a.kind != b.kind || a.slot != b.slot || a.kg != b.kg || (a.kind == GroupItem::LAUNCH &&
+          (a.grid.x != b.grid.x || a.grid.y != b.grid.y || a.grid.z != b.grid.z || a.block.x != b.block.x || a.smem != b.smem || a.arg_size != b.arg_size)))
+        return eae_set_error(EAE_ERR_STATE, "group_train_step: the members' steps differ (different shapes or state)");
+    }
+  }
+  const auto tp2 = std::chrono::steady_clock::now();
+  const unsigned char* argv[64];
+  for (size_t i = 0; i < len; ++i) {
+    const GroupItem& a = recs[0].items[i];
+    hipStream_t st = group_stream(c0, user, a.slot);
+    switch (a.kind) {
+      case GroupItem::LAUNCH:
+        for (int k = 0; k < n; ++k) argv[k] = recs[k].argbuf.data() + recs[k].items[i].arg_off;
+        if (a.fn(a.kg, a.grid, a.block, a.smem, st, argv, n)) return eae_set_error(EAE_ERR_HIP, "group_train_step: a grouped launch failed");
+        break;
+      case GroupItem::EV_RECORD: EAE_HIP(hipEventRecord(a.ev, st)); break;
+      case GroupItem::EV_WAIT: EAE_HIP(hipStreamWaitEvent(st, a.ev, 0)); break;
+      case GroupItem::OP:
+        for (int k = 0; k < n; ++k) if (int e = recs[k].items[i].op(st)) return eae_set_error(EAE_ERR_HIP, "group_train_step: a copy / memset failed"), e;
+        break;
+    }
+  }
+  if (timing) {
+    const auto tp3 = std::chrono::steady_clock::now();
+    t_acc[0] += std::chrono::duration<double, std::micro>(tp1 - tp0).count();
+    t_acc[1] += std::chrono::duration<double, std::micro>(tp2 - tp1).count();
+    t_acc[2] += std::chrono::duration<double, std::micro>(tp3 - tp2).count();
+    if (++t_n == 100) {
+      fprintf(stderr, "[eae group] n=%d items=%zu  record %.1f us  zip %.1f us  enqueue %.1f us\n", n, len, t_acc[0] / 100, t_acc[1] / 100, t_acc[2] / 100);
+      t_acc[0] = t_acc[1] = t_acc[2] = 0; t_n = 0;
+    }
+  }
+  return 0;
 }
 
 extern "C" int eae_encoder_forward(eae_ctx* c, void* stream, const float* x, int B, int train, float* z) {
@@ -1923,7 +2037,7 @@ extern "C" int eae_op_head_ce(void* stream, const float* z, const float* w1, con
   h.logits = logits; h.dz = dz; h.grad_part = (labels && grads) ? gpart : nullptr; h.grad_stride = stride; h.loss_part = ce_part;
   RC(eae_launch_head(st, h));
   if (labels && grads) {
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(stride / 4)), dim3(256), 0, st, gpart, nb, (long)(stride / 4), grads, 1.0f);
+    launch_reduce_slices(st, gpart, nb, (long)(stride / 4), grads, 1.0f);
     EAE_LAUNCH_CHECK();
   }
   if (labels && loss2) RC(eae_launch_ce_mean(st, ce_part, nb, B, loss2));

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "eae_group.h"
 
 typedef uint16_t bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment (4 VGPRs)
@@ -318,9 +319,11 @@ __device__ __forceinline__ void bn_fold_bwd_finish(const BnBwdFold& f, const BnF
   __syncthreads();
 }
 
-// first thread of the grid publishes the stream's progress value (relaxed agent-scope store: bypasses the non-coherent caches)
+// first thread of the grid publishes the stream's progress value (relaxed agent-scope store: bypasses the non-coherent caches).
+// Every z-plane's first workgroup stores: in a grouped launch (eae_group.h) the planes belong to different members, each with its own
+// word; the K-slices of a split-K launch store the same value to the same word.
 __device__ __forceinline__ void eae_signal(unsigned* sig, unsigned val) {
-  if (sig != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+  if (sig != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
     __hip_atomic_store(sig, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -12,15 +12,16 @@ namespace {
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
 int launch(const ConvArgs& a, hipStream_t st) {   // NOLINT
   auto kern = igemm_s2_kernel<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI>;
+  auto kern_g = igemm_s2_kernel_g<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI>;
   constexpr size_t smem = igemm_smem<KIND, BN, TW, TH, NI>();
-  EAE_HIP(eae_smem_attr(reinterpret_cast<const void*>(kern), smem));
+  EAE_HIP(eae_smem_attr(reinterpret_cast<const void*>(eae_rec ? (const void*)kern_g : (const void*)kern), smem));
   const int Hpos = (KIND == KIND_CONV) ? a.Hin / 2 : a.Hin, Wpos = (KIND == KIND_CONV) ? a.Win / 2 : a.Win;
   const int groups = (a.B + NI - 1) / NI;
   const int ntiles = groups * (Hpos / TH) * (Wpos / TW);
   dim3 grid(ntiles * (COUT / BN));        // 1-D: the kernel maps ids to (tile, channel block) XCD-aware
   ConvArgs b = a;
   b.ntiles = ntiles;
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, b);
+  eae_launch(kern, kern_g, grid, dim3(256), smem, st, b);
   EAE_LAUNCH_CHECK();
   return 0;
 }
@@ -44,6 +45,7 @@ static bool ig_mt_th4() { static const bool v = getenv("EAE_IG_MT_TH4") && atoi(
 
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int SRC, int EPI>
 int launch_mt(const ConvArgs& a, hipStream_t st) {   // NOLINT
+  EAE_NO_GROUP("the multi-tile implicit-GEMM kernel");
   void (*kern)(ConvArgs) = igemm_mt_kernel<KIND, CIN, COUT, BN, TW, TH, SRC, EPI>;
   if (a.qs) kern = igemm8_mt_kernel<KIND, CIN, COUT, BN, TW, TH, SRC, EPI>;
   constexpr size_t smem = igemm_mt_smem<KIND, BN, TW, TH>();
@@ -61,6 +63,7 @@ int launch_mt(const ConvArgs& a, hipStream_t st) {   // NOLINT
 // fp8 variant (BASELINE config 5): same geometry, operands converted to fp8 (ConvArgs::qs set by the engine); 16-wide tiles only
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
 int launch8(const ConvArgs& a, hipStream_t st) {   // NOLINT
+  EAE_NO_GROUP("the fp8 implicit-GEMM kernel");
   auto kern = igemm8_s2_kernel<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI>;
   constexpr size_t smem = igemm_smem<KIND, BN, TW, TH, NI>();
   EAE_HIP(eae_smem_attr(reinterpret_cast<const void*>(kern), smem));
@@ -88,15 +91,16 @@ static bool igemm2_on() {
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI, int NBL>
 int launch2(const ConvArgs& a, hipStream_t st) {   // NOLINT
   auto kern = igemm2_s2_kernel<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI, NBL>;
+  auto kern_g = igemm2_s2_kernel_g<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI, NBL>;
   constexpr size_t smem = igemm2_smem<KIND, BN, TW, TH, NI, NBL>();
-  EAE_HIP(eae_smem_attr(reinterpret_cast<const void*>(kern), smem));
+  EAE_HIP(eae_smem_attr(reinterpret_cast<const void*>(eae_rec ? (const void*)kern_g : (const void*)kern), smem));
   const int Hpos = (KIND == KIND_CONV) ? a.Hin / 2 : a.Hin, Wpos = (KIND == KIND_CONV) ? a.Win / 2 : a.Win;
   const int groups = (a.B + NI - 1) / NI;
   const int ntiles = groups * (Hpos / TH) * (Wpos / TW);
   dim3 grid(ntiles * (NBL > 1 ? 1 : COUT / BN));
   ConvArgs b = a;
   b.ntiles = ntiles;
-  hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, b);
+  eae_launch(kern, kern_g, grid, dim3(512), smem, st, b);
   EAE_LAUNCH_CHECK();
   return 0;
 }
@@ -106,13 +110,16 @@ int launch2(const ConvArgs& a, hipStream_t st) {   // NOLINT
 // small vs large: B=64 0.255 vs 0.280, B=128 0.288 vs 0.310, B=256 0.369 vs 0.371) and lose at B=512, so a layer takes them when its
 // large-tile grid has fewer than 256 workgroups.  EAE_IG_SMALL=<mask> overrides (bit 0: conv kind, bit 1: transposed kind).
 static int ig_small_env() { static const int v = getenv("EAE_IG_SMALL") ? atoi(getenv("EAE_IG_SMALL")) : -1; return v; }
+// (eae_geo_mult: members of a grouped step -- K contexts' launches run as one, so the grid that decides is K times the member's)
 static bool conv_small(int B, int Wp, int cout) {
   if (ig_small_env() >= 0) return (ig_small_env() & 1) != 0;
+  B *= eae_geo_mult;
   const int nt = (Wp == 8) ? (B + 1) / 2 : (B + 7) / 8;
   return nt * (cout / 64) < 256;
 }
 static bool deconv_small(int B, int Win, int cout) {
   if (ig_small_env() >= 0) return (ig_small_env() & 2) != 0;
+  B *= eae_geo_mult;
   const int nt = (Win == 8) ? B : (B + 3) / 4;
   return nt * (cout / 64) < 256;
 }

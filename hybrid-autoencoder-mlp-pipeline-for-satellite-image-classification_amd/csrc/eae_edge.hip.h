@@ -150,7 +150,7 @@ struct EdgeArgs {
 // straight from the patch.  The weights are the MFMA A operand: an accumulator lane holds 4 consecutive output channels of
 // one pixel (8-byte tile writes instead of 16 two-byte ones).
 template <int SRC3, int EPI>
-__global__ __launch_bounds__(256) void edge_conv_kernel(EdgeArgs a) {
+__device__ __forceinline__ void edge_conv_body(const EdgeArgs& a) {
   __shared__ __attribute__((aligned(16))) bf16_t p3[E_PATCH];
   // output tile [128][40] (10 KB); the statistics reduction scratch [2][64][32] floats (16 KB) reuses the same memory: TileEpilogue::end()
   // starts with a barrier behind the last read of the tile (31.3 -> 20.7 KB of LDS per block: 7 instead of 5 blocks per CU)
@@ -219,6 +219,10 @@ __global__ __launch_bounds__(256) void edge_conv_kernel(EdgeArgs a) {
   tile_epilogue<32, 32, EPI>(a.c, at, red, 0, blockIdx.x, 128, rowmap);
   EDGE_STAMP(19);
 }
+template <int SRC3, int EPI>
+__global__ __launch_bounds__(256) void edge_conv_kernel(EdgeArgs a) { edge_conv_body<SRC3, EPI>(a); }
+template <int SRC3, int EPI>
+__global__ __launch_bounds__(256) void edge_conv_kernel_g(GroupPack<EdgeArgs> p, int gz) { edge_conv_body<SRC3, EPI>(group_args<EdgeArgs>(gz)); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // R[k][c] = sum_m im2col27(src3)[m][k] * T(side)[m][c]     (weight gradient of conv1 and of deconv4)
@@ -237,7 +241,7 @@ struct EdgeWgradArgs {
 };
 
 template <int SRC3, int SMODE>
-__global__ __launch_bounds__(256) void edge_wgrad_kernel(EdgeWgradArgs a) {
+__device__ __forceinline__ void edge_wgrad_body(const EdgeWgradArgs& a) {
   eae_signal(a.sig, a.sig_val);
   __shared__ __attribute__((aligned(16))) bf16_t p3[E_PATCH];
   // the two operand tiles; the cross-wave reduction image of the epilogue (16 KB) reuses them (41.9 -> 26 KB of LDS per block:
@@ -344,6 +348,10 @@ __global__ __launch_bounds__(256) void edge_wgrad_kernel(EdgeWgradArgs a) {
     }
   }
 }
+template <int SRC3, int SMODE>
+__global__ __launch_bounds__(256) void edge_wgrad_kernel(EdgeWgradArgs a) { edge_wgrad_body<SRC3, SMODE>(a); }
+template <int SRC3, int SMODE>
+__global__ __launch_bounds__(256) void edge_wgrad_kernel_g(GroupPack<EdgeWgradArgs> p, int gz) { edge_wgrad_body<SRC3, SMODE>(group_args<EdgeWgradArgs>(gz)); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // deconv4 forward (all four phases jointly) + sigmoid + MSE loss + its gradient      (R.md:382-383, 622, 649)
@@ -364,7 +372,7 @@ struct Deconv4Args {
 };
 
 template <int SRC>
-__global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
+__device__ __forceinline__ void deconv4_loss_body(const Deconv4Args& a) {
   constexpr int PH = E_TH + 1, PW = E_TW + 1, NPIX = PH * PW;       // 5 x 33 input pixels
   constexpr int NPA = (NPIX * 4 + 255) / 256;
   // the pre-sigmoid tile `sl` (8.7 KB) reuses the patch (13.2 KB) once every wave has read its fragments: 8 blocks per CU
@@ -491,3 +499,7 @@ __global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) {
   }
   EDGE_STAMP(7);
 }
+template <int SRC>
+__global__ __launch_bounds__(256) void deconv4_loss_kernel(Deconv4Args a) { deconv4_loss_body<SRC>(a); }
+template <int SRC>
+__global__ __launch_bounds__(256) void deconv4_loss_kernel_g(GroupPack<Deconv4Args> p, int gz) { deconv4_loss_body<SRC>(group_args<Deconv4Args>(gz)); }

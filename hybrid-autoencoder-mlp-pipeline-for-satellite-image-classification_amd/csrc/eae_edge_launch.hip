@@ -14,7 +14,7 @@ int eae_launch_edge_conv(hipStream_t st, int src3_kind, int epi, const EdgeArgs&
   EdgeArgs a = a0;
   dim3 grid(a.B * (a.H / 2 / E_TH) * (a.W / 2 / E_TW));
   a.c.ntiles = (int)grid.x;
-#define CASE(S, E) if (src3_kind == S && epi == E) { hipLaunchKernelGGL((edge_conv_kernel<S, E>), grid, dim3(256), 0, st, a); EAE_LAUNCH_CHECK(); return 0; }
+#define CASE(S, E) if (src3_kind == S && epi == E) { eae_launch(edge_conv_kernel<S, E>, edge_conv_kernel_g<S, E>, grid, dim3(256), 0, st, a); EAE_LAUNCH_CHECK(); return 0; }
   CASE(SRC3_NCHW_F32, EPI_FWD)
   CASE(SRC3_NHWC4_BF16, EPI_MASK)
   CASE(SRC3_NHWC4_BF16, EPI_PLAIN)
@@ -43,13 +43,14 @@ int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B
   static const int cap = getenv("EAE_EDGE_WGRAD_BLOCKS") ? atoi(getenv("EAE_EDGE_WGRAD_BLOCKS")) : 512;
   // a launch beside the backward-data chain (deconv4's weight gradient, side stream) takes fewer CUs from it with fewer blocks
   static const int cap_side = getenv("EAE_EDGE_WGRAD_SIDE_BLOCKS") ? atoi(getenv("EAE_EDGE_WGRAD_SIDE_BLOCKS")) : 256;
-  const int lim = (src3_kind == SRC3_NHWC4_BF16) ? cap_side : cap;
+  int lim = (src3_kind == SRC3_NHWC4_BF16) ? cap_side : cap;
+  if (eae_geo_mult > 1) lim = lim / eae_geo_mult > 32 ? lim / eae_geo_mult : 32;      // member of a grouped step: the caps are per launch
   int nblocks = a.ntiles < lim ? a.ntiles : lim;
   while ((long long)nblocks * 864 > scratch_floats && nblocks > 1) nblocks /= 2;
   a.tiles_per_block = (a.ntiles + nblocks - 1) / nblocks;
   nblocks = (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
   if ((long long)nblocks * 864 > scratch_floats) return eae_set_error(-2, "edge_wgrad: scratch too small");
-#define CASE(S, M) if (src3_kind == S && smode == M) { if (hook) hook->begin(hook->user, st); hipLaunchKernelGGL((edge_wgrad_kernel<S, M>), dim3(nblocks), dim3(256), 0, st, a); if (hook) hook->end(hook->user, st); EAE_LAUNCH_CHECK(); goto reduce; }
+#define CASE(S, M) if (src3_kind == S && smode == M) { if (hook) hook->begin(hook->user, st); eae_launch(edge_wgrad_kernel<S, M>, edge_wgrad_kernel_g<S, M>, dim3(nblocks), dim3(256), 0, st, a); if (hook) hook->end(hook->user, st); EAE_LAUNCH_CHECK(); goto reduce; }
   CASE(SRC3_NCHW_F32, SRC_BNBWD)
   CASE(SRC3_NHWC4_BF16, SRC_BNRELU)
   CASE(SRC3_NCHW_F32, SRC_RAW)
@@ -58,7 +59,10 @@ int eae_launch_edge_wgrad(hipStream_t st, int src3_kind, const void* src3, int B
 reduce:
   GateArgs tail = GateArgs();      // mid(): the caller's work between the two launches; a gate it returns is waited for in the reduction's tail
   if (mid) { if (int rc = mid(mid_user, &tail)) return rc; }
-  hipLaunchKernelGGL(reduce_slices_tall_kernel, dim3((864 / 4 + 3) / 4), dim3(256), 0, st, scratch, nblocks, (long)(864 / 4), dw, tail);
+  {
+    const ReduceTallArgs ra = {scratch, nblocks, (long)(864 / 4), dw, tail};
+    eae_launch(reduce_slices_tall_kernel, reduce_slices_tall_kernel_g, dim3((864 / 4 + 3) / 4), dim3(256), 0, st, ra);
+  }
   EAE_LAUNCH_CHECK();
   return 0;
 }
@@ -66,8 +70,8 @@ reduce:
 int eae_launch_deconv4_loss(hipStream_t st, int smode, const Deconv4Args& a) {
   if (a.B <= 0 || a.Hin % E_TH || a.Win % E_TW) return eae_set_error(-2, "deconv4: input must be a multiple of 4 x 32");
   dim3 grid(a.B * (a.Hin / E_TH) * (a.Win / E_TW));
-  if (smode == SRC_BNRELU) hipLaunchKernelGGL((deconv4_loss_kernel<SRC_BNRELU>), grid, dim3(256), 0, st, a);
-  else if (smode == SRC_RAW) hipLaunchKernelGGL((deconv4_loss_kernel<SRC_RAW>), grid, dim3(256), 0, st, a);
+  if (smode == SRC_BNRELU) eae_launch(deconv4_loss_kernel<SRC_BNRELU>, deconv4_loss_kernel_g<SRC_BNRELU>, grid, dim3(256), 0, st, a);
+  else if (smode == SRC_RAW) eae_launch(deconv4_loss_kernel<SRC_RAW>, deconv4_loss_kernel_g<SRC_RAW>, grid, dim3(256), 0, st, a);
   else return eae_set_error(-2, "deconv4: source mode not instantiated");
   EAE_LAUNCH_CHECK();
   return 0;
@@ -105,6 +109,7 @@ __global__ EAE_NO_PK __launch_bounds__(256) void sigmoid_bwd_kernel(const float*
 
 int eae_launch_sigmoid_bwd(hipStream_t st, const float* x_hat, const float* dx_hat, void* g4, float* part, int B, int H, int W) {
   const long plane = (long)H * W, tot = plane * B;
+  EAE_NO_GROUP("sigmoid_bwd");
   hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, x_hat, dx_hat, (bf16_t*)g4, part, tot, plane);
   EAE_LAUNCH_CHECK();
   return 0;

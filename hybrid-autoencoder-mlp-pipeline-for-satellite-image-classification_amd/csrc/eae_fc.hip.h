@@ -19,8 +19,9 @@ struct FcNtArgs {
   int M, N, K;
   int klen;                // K-range per grid.z slice (multiple of 64)
   float* part;             // FCE_PARTIAL
-  ConvArgs c;              // FCE_BIAS_BF16 / FCE_MASK: out, bias ([N]), stat_part, yprev, prev_coef ([4][256])
-  BnFold fold;             // BNRELU source: coefficient table of the 256-channel source layer from its accumulators
+  ConvArgs c;              // FCE_BIAS_BF16 / FCE_MASK: out, bias ([N]), stat_part, yprev, prev_coef ([4][256]);
+                           // c.fold: BNRELU source -- coefficient table of the 256-channel source layer from its accumulators
+                           // (no field of its own: eight of these blocks must fit one grouped launch, eae_group.h)
 };
 
 constexpr int FC_KC = 64;
@@ -82,23 +83,24 @@ __device__ __forceinline__ uint4 fc_finish_raw(const FcRaw<MODE>& r, bool valid,
 }
 
 // tile 128 (M) x 64 (N); 4 waves 2x2 (each 64 x 32); K chunks of 64
+// (bz: the workgroup's K-slice index -- blockIdx.z alone, blockIdx.z % gz in a grouped launch)
 template <int AMODE, int EPI>
-__global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs a) {
+__device__ __forceinline__ void fc_nt_body(const FcNtArgs& a, const int bz) {
   eae_signal(a.c.sig, a.c.sig_val);
   __shared__ __attribute__((aligned(16))) bf16_t al[128 * FC_LS];      // A chunk; later the output tile [128][72]
   __shared__ __attribute__((aligned(16))) bf16_t wl[64 * FC_LS];
   __shared__ __attribute__((aligned(16))) float red[2 * 32 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64, kbeg = blockIdx.z * a.klen;
+  const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64, kbeg = bz * a.klen;
   const int kgl = lane >> 4, kg8 = tid & 7;
   f32x4 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   __shared__ float coef_tab[(AMODE == SRC_BNRELU) ? 4 * 256 : 4];
   const float* coefp = a.a.coef;
-  if (AMODE == SRC_BNRELU && a.fold.acc != nullptr) {
-    bn_fold_fwd<256>(a.fold, coef_tab, reinterpret_cast<long long*>(red), blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+  if (AMODE == SRC_BNRELU && a.c.fold.acc != nullptr) {
+    bn_fold_fwd<256>(a.c.fold, coef_tab, reinterpret_cast<long long*>(red), blockIdx.x == 0 && blockIdx.y == 0 && bz == 0);
     coefp = coef_tab;
   }
   if constexpr (EPI == FCE_PARTIAL) {      // the split-K projections: several chunks per workgroup
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs a) {
     }
   }
   if (EPI == FCE_PARTIAL) {
-    float* out = a.part + (size_t)blockIdx.z * a.M * a.N;
+    float* out = a.part + (size_t)bz * a.M * a.N;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -219,12 +221,18 @@ __global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs a) {
   if (EPI == FCE_MASK) tile_epilogue<256, 64, EPI_MASK>(a.c, al, red, c0, tile_id, 128, rowmap);
   else tile_epilogue<256, 64, EPI_PLAIN>(a.c, al, red, c0, tile_id, 128, rowmap);
 }
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256) void fc_nt_kernel(FcNtArgs a) { fc_nt_body<AMODE, EPI>(a, (int)blockIdx.z); }
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256) void fc_nt_kernel_g(GroupPack<FcNtArgs> p, int gz) { fc_nt_body<AMODE, EPI>(group_args<FcNtArgs>(gz), (int)(blockIdx.z % (unsigned)gz)); }
 
 // z (or dz) = bias + sum over K-slices of the split-K partials (+ optional addends), fp32; 16 float4 lanes x 16 slice
 // lanes per block, fixed summation order
-static __global__ EAE_NO_PK __launch_bounds__(256) void fc_splitk_reduce_kernel(const float* __restrict__ part, int nsl, int M, int N,
-                                                                const float* __restrict__ bias, const float* __restrict__ addend,
-                                                                const float* __restrict__ addend2, float* __restrict__ out) {
+struct FcReduceArgs { const float* part; int nsl, M, N; const float* bias; const float* addend; const float* addend2; float* out; };
+static __device__ __forceinline__ EAE_NO_PK void fc_splitk_reduce_body(const FcReduceArgs& a) {
+  const float* __restrict__ part = a.part; const int nsl = a.nsl, M = a.M, N = a.N;
+  const float* __restrict__ bias = a.bias; const float* __restrict__ addend = a.addend; const float* __restrict__ addend2 = a.addend2;
+  float* __restrict__ out = a.out;
   __shared__ float4 red[16][16];
   const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
   const long n4 = (long)M * N / 4;
@@ -253,6 +261,8 @@ static __global__ EAE_NO_PK __launch_bounds__(256) void fc_splitk_reduce_kernel(
     reinterpret_cast<float4*>(out)[i] = r;
   }
 }
+static __global__ EAE_NO_PK __launch_bounds__(256) void fc_splitk_reduce_kernel(FcReduceArgs a) { fc_splitk_reduce_body(a); }
+static __global__ EAE_NO_PK __launch_bounds__(256) void fc_splitk_reduce_kernel_g(GroupPack<FcReduceArgs> p, int gz) { fc_splitk_reduce_body(group_args<FcReduceArgs>(gz)); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // R[i][j] = sum_b P[b][i] * Q[b][j]; block = 64 (i) x 64 (j); whole batch reduced in chunks of 64 rows.
@@ -275,7 +285,7 @@ struct FcTnArgs {
 // c runs when its pieces have arrived, and the slot is re-issued for chunk c + FC_TN_D before the MFMAs of chunk c.
 constexpr int FC_TN_D = 4;
 template <int PMODE, int QMODE>
-__global__ __launch_bounds__(256) void fc_tn_kernel(FcTnArgs a) {
+__device__ __forceinline__ void fc_tn_body(const FcTnArgs& a) {
   __shared__ __attribute__((aligned(16))) bf16_t pl[64 * FC_LS];
   __shared__ __attribute__((aligned(16))) bf16_t ql[64 * FC_LS];
   __shared__ float csum[32][64];
@@ -370,3 +380,7 @@ __global__ __launch_bounds__(256) void fc_tn_kernel(FcTnArgs a) {
     }
   }
 }
+template <int PMODE, int QMODE>
+__global__ __launch_bounds__(256) void fc_tn_kernel(FcTnArgs a) { fc_tn_body<PMODE, QMODE>(a); }
+template <int PMODE, int QMODE>
+__global__ __launch_bounds__(256) void fc_tn_kernel_g(GroupPack<FcTnArgs> p, int gz) { fc_tn_body<PMODE, QMODE>(group_args<FcTnArgs>(gz)); }

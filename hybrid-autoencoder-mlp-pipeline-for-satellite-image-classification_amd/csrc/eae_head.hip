@@ -20,7 +20,7 @@ constexpr int HC = 64;  // logits row stride in LDS = largest class count
 // Row strides are padded to L + 4 / 132 floats: 16-byte aligned rows whose float4 reads by 16 consecutive lanes fall on 16 different
 // bank slots.  Arithmetic stays fp32 fmaf chains (the head is fp32 end to end: <= 5e-5 vs the reference's goldens).
 template <int HR_>
-__global__ EAE_NO_PK __launch_bounds__(256, 5) void head_kernel(HeadArgs a) {     // <= 96 VGPRs: the kernel runs beside the decoder on a side stream, and a wave-specialised igemm2 workgroup (2 x 200 registers per SIMD lane) must still fit beside one of its waves -- at 132 registers dec.deconv1's forward waited for the head's 32 CUs (15 -> 28 us)
+__device__ __forceinline__ EAE_NO_PK void head_body(const HeadArgs& a) {     // <= 96 VGPRs: the kernel runs beside the decoder on a side stream, and a wave-specialised igemm2 workgroup (2 x 200 registers per SIMD lane) must still fit beside one of its waves -- at 132 registers dec.deconv1's forward waited for the head's 32 CUs (15 -> 28 us)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int L = a.L, C = a.C, LS = L + 4, HS = 132;
   float* w1 = sm;                    // [128][LS]
@@ -185,6 +185,10 @@ __global__ EAE_NO_PK __launch_bounds__(256, 5) void head_kernel(HeadArgs a) {   
     gp[128 * L + 128 + C * 128 + tid] = s;
   }
 }
+template <int HR_>
+__global__ EAE_NO_PK __launch_bounds__(256, 5) void head_kernel(HeadArgs a) { head_body<HR_>(a); }
+template <int HR_>
+__global__ EAE_NO_PK __launch_bounds__(256, 5) void head_kernel_g(GroupPack<HeadArgs> p, int gz) { head_body<HR_>(group_args<HeadArgs>(gz)); }
 
 static int head_rows(int L) { return L <= 128 ? 16 : 8; }
 int eae_head_blocks(int B, int L) { const int hr = head_rows(L); return (B + hr - 1) / hr; }
@@ -196,11 +200,12 @@ int eae_launch_head(hipStream_t st, const HeadArgs& a) {
   // the dynamic-LDS limit is an attribute of the kernel ON ONE DEVICE and the request grows with the latent width: keep the
   // largest size granted per (kernel, device) (a process-wide static skipped the attribute for an engine on a second device)
   void (*kern)(HeadArgs) = hr == 16 ? head_kernel<16> : head_kernel<8>;
+  void (*kern_g)(GroupPack<HeadArgs>, int) = hr == 16 ? head_kernel_g<16> : head_kernel_g<8>;
   {
     static thread_local std::vector<std::pair<std::pair<const void*, int>, size_t>> granted;
     int dev = 0;
     EAE_HIP(hipGetDevice(&dev));
-    const void* f = reinterpret_cast<const void*>(kern);
+    const void* f = eae_rec ? reinterpret_cast<const void*>(kern_g) : reinterpret_cast<const void*>(kern);
     size_t* have = nullptr;
     for (auto& g : granted) if (g.first.first == f && g.first.second == dev) have = &g.second;
     if (!have || *have < smem) {
@@ -208,7 +213,7 @@ int eae_launch_head(hipStream_t st, const HeadArgs& a) {
       if (have) *have = smem; else granted.push_back({{f, dev}, smem});
     }
   }
-  hipLaunchKernelGGL(kern, dim3((a.B + hr - 1) / hr), dim3(256), smem, st, a);
+  eae_launch(kern, kern_g, dim3((a.B + hr - 1) / hr), dim3(256), (unsigned)smem, st, a);
   EAE_LAUNCH_CHECK();
   return 0;
 }
@@ -225,8 +230,11 @@ __device__ __forceinline__ double lf_wave_sum(double v) {
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-__global__ EAE_NO_PK __launch_bounds__(256) void loss_finalize_kernel(const float* mse_part, int n_mse, const float* ce_part, int n_ce, float alpha,
-                                                             float inv_numel, float B, float* db4, float* accum, float* last, const unsigned* poison) {
+struct LossFinArgs { const float* mse_part; int n_mse; const float* ce_part; int n_ce; float alpha, inv_numel, B; float* db4; float* accum; float* last; const unsigned* poison; };
+__device__ __forceinline__ EAE_NO_PK void loss_finalize_body(const LossFinArgs& a) {
+  const float* mse_part = a.mse_part; const int n_mse = a.n_mse; const float* ce_part = a.ce_part; const int n_ce = a.n_ce;
+  const float alpha = a.alpha, inv_numel = a.inv_numel, B = a.B;
+  float* db4 = a.db4; float* accum = a.accum; float* last = a.last; const unsigned* poison = a.poison;
   __shared__ double red[4][6];
   const int tid = threadIdx.x;
   double s[6] = {0, 0, 0, 0, 0, 0};
@@ -265,11 +273,13 @@ __global__ EAE_NO_PK __launch_bounds__(256) void loss_finalize_kernel(const floa
     if (last) { last[0] = loss; last[1] = mse; last[2] = cem; }
   }
 }
+__global__ EAE_NO_PK __launch_bounds__(256) void loss_finalize_kernel(LossFinArgs a) { loss_finalize_body(a); }
+__global__ EAE_NO_PK __launch_bounds__(256) void loss_finalize_kernel_g(GroupPack<LossFinArgs> p, int gz) { loss_finalize_body(group_args<LossFinArgs>(gz)); }
 
 int eae_launch_loss_finalize(hipStream_t st, const float* mse_part, int n_mse, const float* ce_part, int n_ce, float alpha,
                              double numel, int B, float* db4, float* accum, float* last, const unsigned* poison) {
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, mse_part, n_mse, ce_part, n_ce, alpha,
-                     (float)(1.0 / numel), (float)B, db4, accum, last, poison);
+  const LossFinArgs la = {mse_part, n_mse, ce_part, n_ce, alpha, (float)(1.0 / numel), (float)B, db4, accum, last, poison};
+  eae_launch(loss_finalize_kernel, loss_finalize_kernel_g, dim3(1), dim3(256), 0, st, la);
   EAE_LAUNCH_CHECK();
   return 0;
 }
@@ -282,6 +292,7 @@ __global__ EAE_NO_PK void ce_mean_kernel(const float* ce_part, int n, float B, f
   out2[0] = (float)(s / B); out2[1] = (float)c;
 }
 int eae_launch_ce_mean(hipStream_t st, const float* ce_part, int n, int B, float* out2) {
+  EAE_NO_GROUP("ce_mean");
   hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(64), 0, st, ce_part, n, (float)B, out2);
   EAE_LAUNCH_CHECK();
   return 0;

@@ -694,6 +694,11 @@ template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, 
 __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void igemm_s2_kernel(ConvArgs a) {
   igemm_body<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI, 0>(a);
 }
+// grouped twin (eae_group.h): workgroup z runs the body with member z's arguments
+template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
+__global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void igemm_s2_kernel_g(GroupPack<ConvArgs> p, int gz) {
+  igemm_body<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI, 0>(group_args<ConvArgs>(gz));
+}
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
 __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void igemm8_s2_kernel(ConvArgs a) {
   igemm_body<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI, 1>(a);

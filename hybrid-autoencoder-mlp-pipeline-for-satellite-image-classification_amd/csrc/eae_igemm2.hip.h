@@ -27,7 +27,7 @@ constexpr size_t igemm2_smem() {
 }
 
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI, int NBL>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm2_s2_kernel(ConvArgs a) {
+__device__ __forceinline__ void igemm2_body(const ConvArgs& a) {
   using G = Geo<KIND, TW, TH, NI>;
   static_assert(G::P == 64 || G::P == 128, "tile must hold 64 or 128 positions");
   static_assert(CIN % 32 == 0 && CIN >= 64 && COUT % BN == 0 && (BN == 32 || BN == 64), "shape");
@@ -304,4 +304,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     epi.end(a, red, n0, tile_id);
     EAE_STAMP_T(2, 0);
   }
+}
+
+template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI, int NBL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm2_s2_kernel(ConvArgs a) {
+  igemm2_body<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI, NBL>(a);
+}
+template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI, int NBL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm2_s2_kernel_g(GroupPack<ConvArgs> p, int gz) {
+  igemm2_body<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI, NBL>(group_args<ConvArgs>(gz));
 }

@@ -28,6 +28,7 @@ inline hipError_t eae_smem_attr(const void* func, size_t bytes) {
   return e;
 }
 
+#include "eae_group.h"
 #include "eae_misc.h"
 #include "eae_head.h"
 // optional bracket around the MAIN kernel of a launcher that enqueues more than one (weight gradient + slice reduction)

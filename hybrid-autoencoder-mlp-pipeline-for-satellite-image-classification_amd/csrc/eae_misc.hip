@@ -127,12 +127,14 @@ __global__ EAE_NO_PK void bn_bwd_coef_kernel(const double* __restrict__ sums, in
   coef_bwd[2 * C + ch] = -A * db / count - Bc * mean;
 }
 int eae_launch_bn_bwd_reduce(hipStream_t st, const float* part, int ntiles, int C, double* sums, float* dgamma, float* dbeta) {
+  EAE_NO_GROUP("bn_bwd_reduce_kernel");
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C), dim3(256), 0, st, part, ntiles, C, sums, dgamma, dbeta);
   EAE_LAUNCH_CHECK();
   return 0;
 }
 int eae_launch_bn_bwd_coef(hipStream_t st, const double* sums, int C, long long count, const float* gamma, const float* coef_fwd,
                            float* coef_bwd) {
+  EAE_NO_GROUP("bn_bwd_coef_kernel");
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sums, C, (float)count, gamma, coef_fwd, coef_bwd);
   EAE_LAUNCH_CHECK();
   return 0;
@@ -140,6 +142,7 @@ int eae_launch_bn_bwd_coef(hipStream_t st, const double* sums, int C, long long 
 
 int eae_launch_bn_finalize(hipStream_t st, const float* part, int ntiles, int C, long long count, const float* gamma,
                            const float* beta, float* rm, float* rv, long long* nbt, float momentum, float eps, float* coef) {
+  EAE_NO_GROUP("bn_finalize_kernel");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, part, ntiles, C, (float)count, gamma, beta, rm,
                      rv, nbt, momentum, eps, coef);
   EAE_LAUNCH_CHECK();
@@ -147,12 +150,14 @@ int eae_launch_bn_finalize(hipStream_t st, const float* part, int ntiles, int C,
 }
 int eae_launch_bn_eval_coef(hipStream_t st, int C, const float* gamma, const float* beta, const float* rm, const float* rv,
                             float eps, float* coef) {
+  EAE_NO_GROUP("bn_eval_coef_kernel");
   hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, C, gamma, beta, rm, rv, eps, coef);
   EAE_LAUNCH_CHECK();
   return 0;
 }
 int eae_launch_bn_bwd_finalize(hipStream_t st, const float* part, int ntiles, int C, long long count, const float* gamma,
                                const float* coef_fwd, float* dgamma, float* dbeta, float* coef_bwd) {
+  EAE_NO_GROUP("bn_bwd_finalize_kernel");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, part, ntiles, C, (float)count, gamma,
                      coef_fwd, dgamma, dbeta, coef_bwd);
   EAE_LAUNCH_CHECK();
@@ -173,16 +178,25 @@ int eae_launch_bn_bwd_finalize(hipStream_t st, const float* part, int ntiles, in
 __global__ EAE_NO_PK __launch_bounds__(64) void gate_kernel(GateArgs g) {
   if (threadIdx.x == 0) gate_wait(g);
 }
-__global__ EAE_NO_PK void signal_kernel(unsigned* word, unsigned val) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__global__ EAE_NO_PK __launch_bounds__(64) void gate_kernel_g(GroupPack<GateArgs> p, int gz) {      // grouped twins (eae_group.h): one wave per member
+  if (threadIdx.x == 0) gate_wait(group_args<GateArgs>(gz));
+}
+struct SignalArgs { unsigned* word; unsigned val; };
+__global__ EAE_NO_PK void signal_kernel(SignalArgs a) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(a.word, a.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ EAE_NO_PK void signal_kernel_g(GroupPack<SignalArgs> p, int gz) {
+  const SignalArgs a = group_args<SignalArgs>(gz);
+  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(a.word, a.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 int eae_launch_gate(hipStream_t st, const GateArgs& g) {
-  hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, st, g);
+  eae_launch(gate_kernel, gate_kernel_g, dim3(1), dim3(64), 0, st, g);
   EAE_LAUNCH_CHECK();
   return 0;
 }
 int eae_launch_signal(hipStream_t st, unsigned* word, unsigned val) {
-  hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, st, word, val);
+  const SignalArgs sa = {word, val};
+  eae_launch(signal_kernel, signal_kernel_g, dim3(1), dim3(64), 0, st, sa);
   EAE_LAUNCH_CHECK();
   return 0;
 }
@@ -258,8 +272,10 @@ __device__ __forceinline__ float pack_fetch(const PackDesc& d, const float* __re
   }
 }
 
-__global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc* __restrict__ descs, const float* __restrict__ params,
-                                                        uint8_t* __restrict__ pack_base, Fp8State* __restrict__ q, unsigned* __restrict__ clear_word) {
+struct PackAllArgs { const PackDesc* descs; const float* params; uint8_t* pack_base; Fp8State* q; unsigned* clear_word; };
+__device__ __forceinline__ EAE_NO_PK void pack_all_body(const PackAllArgs& pa) {
+  const PackDesc* __restrict__ descs = pa.descs; const float* __restrict__ params = pa.params; uint8_t* __restrict__ pack_base = pa.pack_base;
+  Fp8State* __restrict__ q = pa.q; unsigned* __restrict__ clear_word = pa.clear_word;
   if (clear_word != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *clear_word = 0u;
   const PackDesc d = descs[blockIdx.y];
   const float* src = params + d.src_off;
@@ -416,10 +432,17 @@ __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(const PackDesc*
     else reinterpret_cast<bf16_t*>(pack_base + d.dst_off)[i] = (bf16_t)f2bf(v);
   }
 }
+__global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel(PackAllArgs a) { pack_all_body(a); }
+__global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel_g(GroupPack<PackAllArgs> p, int gz) { pack_all_body(group_args<PackAllArgs>(gz)); }
 
 int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base, Fp8State* q, unsigned* clear_word,
                         int blocks_per_desc) {
-  hipLaunchKernelGGL(pack_all_kernel, dim3(blocks_per_desc > 0 ? blocks_per_desc : 256, ndesc), dim3(256), 0, st, descs_dev, params, (uint8_t*)pack_base, q, clear_word);
+  const PackAllArgs pa = {descs_dev, params, (uint8_t*)pack_base, q, clear_word};
+  if (blocks_per_desc <= 0) blocks_per_desc = 256;
+  // member of a grouped step: the launch carries eae_geo_mult members' descriptors (8 x 256 x ~20 workgroups, most of them with a few
+  // hundred elements, took 54 us: the dispatch of 41 K workgroups, not the 62 MB they move)
+  if (eae_geo_mult > 1) blocks_per_desc = blocks_per_desc / eae_geo_mult > 16 ? blocks_per_desc / eae_geo_mult : 16;
+  eae_launch(pack_all_kernel, pack_all_kernel_g, dim3(blocks_per_desc, ndesc), dim3(256), 0, st, pa);
   EAE_LAUNCH_CHECK();
   return 0;
 }
@@ -471,6 +494,7 @@ __global__ EAE_NO_PK void fp8_scales_kernel(Fp8State* q) {
   }
 }
 int eae_launch_fp8_scales(hipStream_t st, Fp8State* q) {
+  EAE_NO_GROUP("fp8_scales_kernel");
   hipLaunchKernelGGL(fp8_scales_kernel, dim3(1), dim3(64), 0, st, q);
   EAE_LAUNCH_CHECK();
   return 0;
@@ -488,11 +512,16 @@ void eae_fp8_state_init(Fp8State* h) {
 // Fused multi-tensor Adam over the flat fp32 arenas (torch.optim.Adam defaults, R.md:624; L2 decay for the MLP, R.md:2625)
 //   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ EAE_NO_PK __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, long n4, float b1, float b2, float step_size,
-                                                    float bc2_sqrt, float eps, float wd, float gscale, uint4* __restrict__ zbuf, long zn16,
-                                                    const unsigned* __restrict__ bad, const unsigned* __restrict__ bad2, float* __restrict__ nan_out,
-                                                    int nan_fill) {
+struct AdamArgs {
+  float* p; const float* g; float* m; float* v; long n4; float b1, b2, step_size, bc2_sqrt, eps, wd, gscale; uint4* zbuf; long zn16;
+  const unsigned* bad; const unsigned* bad2; float* nan_out; int nan_fill;
+};
+__device__ __forceinline__ EAE_NO_PK void adam_body(const AdamArgs& aa) {
+  float* __restrict__ p = aa.p; const float* __restrict__ g = aa.g; float* __restrict__ m = aa.m; float* __restrict__ v = aa.v;
+  const long n4 = aa.n4; const float b1 = aa.b1, b2 = aa.b2, step_size = aa.step_size, bc2_sqrt = aa.bc2_sqrt, eps = aa.eps, wd = aa.wd, gscale = aa.gscale;
+  uint4* __restrict__ zbuf = aa.zbuf; const long zn16 = aa.zn16;
+  const unsigned* __restrict__ bad = aa.bad; const unsigned* __restrict__ bad2 = aa.bad2; float* __restrict__ nan_out = aa.nan_out;
+  const int nan_fill = aa.nan_fill;
   // side job: clear the BatchNorm statistics accumulators for the next step (every consumer of this step has finished)
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zn16; i += (long)gridDim.x * 256) zbuf[i] = make_uint4(0, 0, 0, 0);
   // a side-stream gate of this context has timed out at some point (sticky word): gradients may have been computed from stale
@@ -531,6 +560,8 @@ __global__ EAE_NO_PK __launch_bounds__(256) void adam_kernel(float* __restrict__
     reinterpret_cast<float4*>(v)[i] = vv;
   }
 }
+__global__ EAE_NO_PK __launch_bounds__(256) void adam_kernel(AdamArgs a) { adam_body(a); }
+__global__ EAE_NO_PK __launch_bounds__(256) void adam_kernel_g(GroupPack<AdamArgs> p, int gz) { adam_body(group_args<AdamArgs>(gz)); }
 
 // Same update with the per-step scalars (lr/bias_correction1, sqrt(bias_correction2), weight decay) read from device memory,
 // so that a captured hipGraph of the whole train step can be replayed while the step count advances.
@@ -571,12 +602,14 @@ int eae_launch_adam_dyn(hipStream_t st, float* p, const float* g, float* m, floa
   long n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
+  EAE_NO_GROUP("adam_dyn_kernel");
   hipLaunchKernelGGL(adam_dyn_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4, (float)b1, (float)b2, (float)eps, dyn, bad, bad2, nan_out);
   EAE_LAUNCH_CHECK();
   return 0;
 }
 int eae_launch_set_dyn(hipStream_t st, float* dyn, double lr, double b1, double b2, double wd, long long step) {
   double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+  EAE_NO_GROUP("set_dyn_kernel");
   hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, st, dyn, (float)(lr / bc1), (float)sqrt(bc2), (float)wd);
   EAE_LAUNCH_CHECK();
   return 0;
@@ -596,8 +629,10 @@ int eae_launch_adam_scaled(hipStream_t st, float* p, const float* g, float* m, f
   int blocks = (int)((n4 + 255) / 256);
   if (max_blocks <= 0) max_blocks = 2048;
   if (blocks > max_blocks) blocks = max_blocks;
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n4, (float)b1, (float)b2, (float)(lr / bc1),
-                     (float)sqrt(bc2), (float)eps, (float)wd, gscale, (uint4*)zero_buf, (long)(zero_bytes / 16), bad, bad2, nan_out, nan_fill);
+  if (eae_geo_mult > 1) blocks = blocks / eae_geo_mult > 64 ? blocks / eae_geo_mult : (blocks < 64 ? blocks : 64);      // member of a grouped step
+  const AdamArgs aa = {p, g, m, v, n4, (float)b1, (float)b2, (float)(lr / bc1), (float)sqrt(bc2), (float)eps, (float)wd, gscale,
+                       (uint4*)zero_buf, (long)(zero_bytes / 16), bad, bad2, nan_out, nan_fill};
+  eae_launch(adam_kernel, adam_kernel_g, dim3(blocks), dim3(256), 0, st, aa);
   EAE_LAUNCH_CHECK();
   return 0;
 }
@@ -671,6 +706,7 @@ int eae_launch_augment(hipStream_t st, const void* in_u8, float* out, int B, int
                        unsigned long long step, const int* params, const float* noise) {
   if (!in_u8 || !out || B <= 0 || H <= 0 || W <= 0) return eae_set_error(-2, "augment: bad argument");
   const long tot = (long)B * H * W;
+  EAE_NO_GROUP("augment_kernel");
   hipLaunchKernelGGL(augment_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const uint8_t*)in_u8, out, B, H, W, train, std,
                      seed, step, params, noise);
   EAE_LAUNCH_CHECK();

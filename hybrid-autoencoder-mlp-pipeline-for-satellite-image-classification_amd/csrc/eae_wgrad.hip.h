@@ -318,6 +318,10 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_s2_kernel(WgradArgs a) {
   wgrad_body<CS, CB, TW, TH, NI, SMODE, BMODE, 0>(a);
 }
 template <int CS, int CB, int TW, int TH, int NI, int SMODE, int BMODE>
+__global__ __launch_bounds__(WG_THREADS, 3) void wgrad_s2_kernel_g(GroupPack<WgradArgs> p, int gz) {      // grouped twin (eae_group.h)
+  wgrad_body<CS, CB, TW, TH, NI, SMODE, BMODE, 0>(group_args<WgradArgs>(gz));
+}
+template <int CS, int CB, int TW, int TH, int NI, int SMODE, int BMODE>
 __global__ __launch_bounds__(WG_THREADS, 3) void wgrad8_s2_kernel(WgradArgs a) {
   wgrad_body<CS, CB, TW, TH, NI, SMODE, BMODE, 1>(a);
 }
@@ -352,22 +356,31 @@ __device__ __forceinline__ void reduce_slices_body(const float* __restrict__ par
 }
 
 // out[i] = sum_s part[s][i]
-static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ part, int nslices, long n4,
-                                                                   float* __restrict__ out, float scale) {
-  reduce_slices_body(part, nslices, n4, [=](long i, float4 r) {
+struct ReduceArgs { const float* part; int nslices; long n4; float* out; float scale; };
+static __device__ __forceinline__ EAE_NO_PK void reduce_slices_run(const ReduceArgs& a) {
+  float* __restrict__ out = a.out;
+  const float scale = a.scale;
+  reduce_slices_body(a.part, a.nslices, a.n4, [=](long i, float4 r) {
     r.x *= scale; r.y *= scale; r.z *= scale; r.w *= scale;
     reinterpret_cast<float4*>(out)[i] = r;
   });
 }
+static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_kernel(ReduceArgs a) { reduce_slices_run(a); }
+static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_kernel_g(GroupPack<ReduceArgs> p, int gz) { reduce_slices_run(group_args<ReduceArgs>(gz)); }
 
 static inline unsigned reduce_slices_grid(long n4) { return (unsigned)((n4 + 15) / 16); }
+static inline void launch_reduce_slices(hipStream_t st, const float* part, int nslices, long n4, float* out, float scale) {
+  const ReduceArgs ra = {part, nslices, n4, out, scale};
+  eae_launch(reduce_slices_kernel, reduce_slices_kernel_g, dim3(reduce_slices_grid(n4)), dim3(256), 0, st, ra);
+}
 
 // Tall variant for few outputs and many slices (conv1 / deconv4 weight gradients: 216 float4, 512 slices): 4 float4 columns
 // x 64 slice lanes per block -> 4x the blocks and a quarter of the serial loads per thread; fixed summation order.
 // tail: an optional gate (eae_misc.h GateArgs, same protocol as gate_kernel) that block 0 waits for AFTER its share of the reduction,
 // so the kernels behind this one on the stream also follow the signalling streams' work.
-static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_tall_kernel(const float* __restrict__ part, int nslices, long n4,
-                                                                                float* __restrict__ out, GateArgs tail) {
+struct ReduceTallArgs { const float* part; int nslices; long n4; float* out; GateArgs tail; };
+static __device__ __forceinline__ EAE_NO_PK void reduce_slices_tall_body(const ReduceTallArgs& a) {
+  const float* __restrict__ part = a.part; const int nslices = a.nslices; const long n4 = a.n4; float* __restrict__ out = a.out;
   __shared__ float4 red[64][4];
   const int lx = threadIdx.x & 3, ly = threadIdx.x >> 2;
   const long i = (long)blockIdx.x * 4 + lx;
@@ -390,5 +403,7 @@ static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_tall_kerne
     for (int k = 1; k < 64; ++k) { r.x += red[k][lx].x; r.y += red[k][lx].y; r.z += red[k][lx].z; r.w += red[k][lx].w; }
     reinterpret_cast<float4*>(out)[i] = r;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && tail.n) gate_wait(tail);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.tail.n) gate_wait(a.tail);
 }
+static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_tall_kernel(ReduceTallArgs a) { reduce_slices_tall_body(a); }
+static __global__ EAE_NO_PK __launch_bounds__(256) void reduce_slices_tall_kernel_g(GroupPack<ReduceTallArgs> p, int gz) { reduce_slices_tall_body(group_args<ReduceTallArgs>(gz)); }

@@ -27,7 +27,8 @@ int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_fl
   (void)parsed;
   // enc.conv2's weight gradient is the last one of the step: it runs in the tail, beside conv2's backward-data and conv1's weight gradient only
   constexpr bool LAST = (CS == 64 && (SM == SRC_BNBWD || SM == SRC_RAWG));
-  const int wgs = LAST ? wgs_last : (nblk == 1 ? wgs_one : wgs_wide);
+  int wgs = LAST ? wgs_last : (nblk == 1 ? wgs_one : wgs_wide);
+  if (eae_geo_mult > 1) wgs = wgs / eae_geo_mult > 8 ? wgs / eae_geo_mult : 8;      // member of a grouped step: the grid sizes are per launch
   int slices = wgs / nblk;
   if (slices < 1) slices = 1;
   if (slices > ntiles) slices = ntiles;
@@ -40,17 +41,19 @@ int launch(const WgradArgs& a0, int ntiles, float* scratch, long long scratch_fl
   a.nslices = slices;
   constexpr size_t smem = WgGeo<TW, TH, NI>::smem();
   void (*kern)(WgradArgs) = wgrad_s2_kernel<CS, CB, TW, TH, NI, SM, BM>;
+  void (*kern_g)(GroupPack<WgradArgs>, int) = wgrad_s2_kernel_g<CS, CB, TW, TH, NI, SM, BM>;
   if (a.qs) {                                // fp8 variant (BASELINE config 5): built for the 16 x 8 tiles only
+    EAE_NO_GROUP("the fp8 weight-gradient kernel");
     if constexpr (TW == 16) kern = wgrad8_s2_kernel<CS, CB, TW, TH, NI, SM, BM>;
     else return eae_set_error(-2, "wgrad: the fp8 variant needs small maps that are multiples of 8 x 16");
   }
-  EAE_HIP(eae_smem_attr(reinterpret_cast<const void*>(kern), smem));
+  EAE_HIP(eae_smem_attr(eae_rec ? reinterpret_cast<const void*>(kern_g) : reinterpret_cast<const void*>(kern), smem));
   if (hook) hook->begin(hook->user, st);
-  hipLaunchKernelGGL(kern, dim3(slices * nblk), dim3(WG_THREADS), smem, st, a);
+  eae_launch(kern, kern_g, dim3(slices * nblk), dim3(WG_THREADS), smem, st, a);
   if (hook) hook->end(hook->user, st);
   EAE_LAUNCH_CHECK();
   if (slices == 1) return 0;
-  hipLaunchKernelGGL(reduce_slices_kernel, dim3(reduce_slices_grid(sz / 4)), dim3(256), 0, st, scratch, slices, (long)(sz / 4), dw, 1.0f);
+  launch_reduce_slices(st, scratch, slices, (long)(sz / 4), dw, 1.0f);
   EAE_LAUNCH_CHECK();
   return 0;
 }

@@ -275,6 +275,26 @@ class AEEngine:
         io, keep = self._io(x, labels, True, head, alpha, x_hat)
         check(self.lib.eae_ae_train_step(self.ctx, _stream(), C.byref(io), float(lr)))
 
+    @staticmethod
+    def group_train_step(engines, xs, labels, alphas, lrs, head=True):
+        """One iteration of the batch loop for SEVERAL configurations of the grid at once (R.md:599-711: same architecture, own
+        alpha / lr / parameters / batches): include/eae.h eae_group_train_step -- one sequence of grouped launches instead of one per
+        engine.  engines: same shape, same device; xs / labels: one batch each (same batch size)."""
+        n = len(engines)
+        e0 = engines[0]
+        if any(e.device != e0.device for e in engines):
+            raise RuntimeError("group_train_step: the engines must live on one device")
+        ios = (EaeStepIO * n)()
+        keep = []
+        for k, e in enumerate(engines):
+            io, kp = e._io(xs[k], labels[k], True, head, alphas[k])
+            ios[k] = io
+            keep.append(kp)
+        ctxs = (C.c_void_p * n)(*[e.ctx for e in engines])
+        lr_arr = (C.c_float * n)(*[float(v) for v in lrs])
+        with torch.cuda.device(e0.device):
+            check(e0.lib.eae_group_train_step(ctxs, n, _stream(), ios, lr_arr))
+
     @_on_device
     def encoder(self, x, train=False):
         b = x.shape[0]

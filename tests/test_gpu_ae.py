@@ -461,6 +461,58 @@ def test_split_optimizer_is_bitwise_the_single_launch_one(monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("n,b", [(3, 16), (8, 64), (10, 8)])
+def test_grouped_step_is_bitwise_each_configuration_alone(n, b):
+    """eae_group_train_step (R.md:599-711: the grid's configurations share the architecture, not alpha / lr / weights / batches): n engines
+    stepped by ONE sequence of grouped launches.  Every member ends bitwise where it ends when it is stepped alone with the same tile
+    geometries (eae_set_geometry_mult(n): the launchers then choose grids as the grouped step does) -- parameters, Adam moments,
+    BatchNorm buffers, the device-side loss sums, and the next eval forward.  n = 10 > 8: more members than one launch carries."""
+    from eae_amd import _lib
+    from eae_amd.engine import AEEngine
+    lib = _lib.load()
+    alphas = [35.0 + 3.0 * k for k in range(n)]
+    lrs = [1e-3 * (1 + k % 3) for k in range(n)]
+    data = [tuple(_cuda(t) for t in gu.make_images(b, 200 + k)) for k in range(n)]
+
+    def fresh():
+        out = []
+        for k in range(n):
+            m = _model()
+            g = torch.Generator(device="cuda").manual_seed(900 + k)
+            with torch.no_grad():
+                for p_ in m.parameters():          # own weights per member
+                    p_.add_(0.02 * p_.abs().mean() * torch.randn(p_.shape, device="cuda", generator=g))
+            out.append((m, _engine(m, max_batch=64)))
+        return out
+
+    def snap(e, xd, yd, a):
+        xh, lg, z = e.forward(xd, labels=yd, train=False, alpha=a)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (e.params, e.adam_m, e.adam_v, e.bn_running, e.loss_accum, e.loss_last, xh, lg, z)]
+
+    grouped = fresh()
+    for _ in range(3):
+        AEEngine.group_train_step([e for _, e in grouped], [d[0] for d in data], [d[1] for d in data], alphas, lrs)
+    torch.cuda.synchronize()
+    assert all(e.gate_timeouts() == 0 for _, e in grouped)
+    got = [snap(e, data[k][0], data[k][1], alphas[k]) for k, (_, e) in enumerate(grouped)]
+    del grouped
+    alone = fresh()
+    _lib.check(lib.eae_set_geometry_mult(n))
+    try:
+        for k, (_, e) in enumerate(alone):
+            for _ in range(3):
+                e.train_step(data[k][0], data[k][1], alphas[k], lrs[k])
+    finally:
+        _lib.check(lib.eae_set_geometry_mult(1))
+    want = [snap(e, data[k][0], data[k][1], alphas[k]) for k, (_, e) in enumerate(alone)]
+    for k in range(n):
+        for a, w in zip(got[k], want[k]):
+            assert torch.equal(a, w), k
+    # (and the members are different trainings: not one result n times)
+    assert not torch.equal(got[0][0], got[1][0])
+
+
 def test_data_parallel_trainer_world1_rccl():
     """The DP step (grad_step -> bucketed all-reduce over RCCL -> adam_step) on a 1-rank NCCL group equals the fused
     single-GPU train_step bit for bit (the multi-rank arithmetic is covered on CPU by tests/test_dp_gloo.py)."""
