@@ -156,29 +156,30 @@ def config5_leg(batch=128, steps=20, warmup=5, roofline=True):
     return res
 
 
-def grid_b64_leg(k=int(os.environ.get("EAE_GRID_K", "4")), steps=150, warmup=15):
-    """The reference's REAL workload (R.md:246, 599-711): batch 64, a grid of independent configurations.  K engine contexts, each on
-    its own stream and stepped from its own host thread (train.run_concurrent -- what grid_search_autoencoder(concurrent=K) uses), run
-    the joint train step at B=64 at the same time; `images_per_s` is the aggregate over the K configurations, `k1` the same loop with
-    one configuration."""
+def grid_b64_leg(k=int(os.environ.get("EAE_GRID_K", "8")), steps=150, warmup=15):
+    """The reference's REAL workload (R.md:246, 599-711): batch 64, a grid of independent configurations.  `grouped`: K engine contexts
+    stepped by ONE sequence of grouped launches per step (include/eae.h eae_group_train_step -- what grid_search_autoencoder(grouped=K)
+    uses); `concurrent`: the round-3 way, 4 contexts on one stream + host thread each (train.run_concurrent); `k1`: one configuration.
+    `images_per_s` is the aggregate over the K configurations of the grouped leg."""
     import eae_amd
-    from eae_amd.engine import engine_for
+    from eae_amd.engine import AEEngine, engine_for
     from eae_amd import train as T
     res = {"workload": "BASELINE configs[2]'s step at the notebook's batch size 64 (R.md:246): K independent (alpha, lr) configurations of "
-                       "the grid R.md:599-711 trained concurrently on one GPU, one engine context + ONE stream + host thread each", "batch": 64}
+                       "the grid R.md:599-711 trained at the same time on one GPU", "batch": 64}
     x, y = make_batch(64, torch.device("cuda"), seed=4321)
-    graph = os.environ.get("EAE_GRID_GRAPH", "0") == "1"      # replay measured slower than eager here (0.7-0.8x): see train.grid_search_autoencoder
-    res["graph_replay"] = graph
-    for kk in (1, k):
+
+    def build(n, single_stream):
         engs = []
-        for i in range(kk):
+        for i in range(n):
             torch.manual_seed(100 + i)
             m = eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=10).cuda().train()
-            if kk >= 3:
+            if single_stream:
                 m._eae_side_streams = -1          # what grid_search_autoencoder(concurrent >= 3) does: one stream per context
-            e = engine_for(m, max_batch=64)
-            e.set_graph(graph and kk > 1)         # K concurrent configurations are bound by the host's launch rate: one replay per step
-            engs.append((m, e))
+            engs.append((m, engine_for(m, max_batch=64)))
+        return engs
+
+    for name, kk in (("k1", 1), ("concurrent", 4)):
+        engs = build(kk, kk >= 3)
 
         def job_of(e, n):
             def job():
@@ -192,11 +193,26 @@ def grid_b64_leg(k=int(os.environ.get("EAE_GRID_K", "4")), steps=150, warmup=15)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         bad = [e.gate_timeouts() for _, e in engs]
-        res["k1" if kk == 1 else "concurrent"] = {"configs": kk, "steps_each": steps, "images_per_s": round(kk * steps * 64 / el, 1),
-                                                  "ms_per_step_per_config": round(1e3 * el / steps, 4), "gate_timeouts": sum(1 for b in bad if b)}
+        res[name] = {"configs": kk, "steps_each": steps, "images_per_s": round(kk * steps * 64 / el, 1),
+                     "ms_per_step_per_config": round(1e3 * el / steps, 4), "gate_timeouts": sum(1 for b in bad if b)}
         del engs
         torch.cuda.empty_cache()
-    res["images_per_s"] = res["concurrent"]["images_per_s"]
+    engs = build(k, False)
+    es = [e for _, e in engs]
+    xs, ys, al, lr = [x] * k, [y] * k, [ALPHA + i for i in range(k)], [1e-3] * k
+    for _ in range(warmup):
+        AEEngine.group_train_step(es, xs, ys, al, lr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        AEEngine.group_train_step(es, xs, ys, al, lr)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    res["grouped"] = {"configs": k, "steps_each": steps, "images_per_s": round(k * steps * 64 / el, 1), "ms_per_group_step": round(1e3 * el / steps, 4),
+                      "gate_timeouts": sum(1 for e in es if e.gate_timeouts())}
+    del engs, es
+    torch.cuda.empty_cache()
+    res["images_per_s"] = res["grouped"]["images_per_s"]
     return res
 
 

@@ -68,7 +68,8 @@ _PROTOS = {
     "eae_dp_broadcast": (C.c_int, [vp, vp, vp, C.c_longlong, C.c_int]),
     "eae_ae_dp_train_step": (C.c_int, [vp, vp, C.POINTER(EaeStepIO), C.c_float, C.c_int]),
     "eae_ae_train_step": (C.c_int, [vp, vp, C.POINTER(EaeStepIO), C.c_float]),
-    "eae_group_train_step": (C.c_int, [C.POINTER(vp), C.c_int, vp, C.POINTER(EaeStepIO), C.POINTER(C.c_float)]),
+    "eae_group_train_step": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, vp, C.POINTER(EaeStepIO), C.POINTER(C.c_float)]),
+    "eae_group_forward": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, vp, C.POINTER(EaeStepIO)]),
     "eae_set_geometry_mult": (C.c_int, [C.c_int]),
     "eae_sync_bn_acc_elems": (C.c_longlong, [vp]),
     "eae_set_sync_bn": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),

@@ -1555,35 +1555,39 @@ extern "C" int eae_set_geometry_mult(int mult) {
   return 0;
 }
 
-extern "C" int eae_group_train_step(eae_ctx* const* ctxs, int n, void* stream, const eae_step_io* ios, const float* lrs) {
-  if (!ctxs || !ios || !lrs || n < 1 || n > 64) return eae_set_error(EAE_ERR_ARG, "group_train_step: 1..64 contexts, one io block and one lr each");
-  if (eae_rec) return eae_set_error(EAE_ERR_STATE, "group_train_step: already recording on this thread");
+namespace {
+// what = 0: eae_ae_train_step's eager path (lrs required); 1: eae_ae_forward
+int group_run(int what, eae_ctx* const* ctxs, int n, int mult, void* stream, const eae_step_io* ios, const float* lrs) {
+  if (!ctxs || !ios || (what == 0 && !lrs) || n < 1 || n > 64) return eae_set_error(EAE_ERR_ARG, "group call: 1..64 contexts, one io block (and one lr) each");
+  if (mult == 0) mult = n;
+  if (mult < n || mult > 64) return eae_set_error(EAE_ERR_ARG, "group call: geometry_mult must be 0 (= n) or n..64");
+  if (eae_rec) return eae_set_error(EAE_ERR_STATE, "group call: already recording on this thread");
   hipStream_t user = (hipStream_t)stream;
   eae_ctx* c0 = ctxs[0];
   for (int k = 0; k < n; ++k) {
     eae_ctx* c = ctxs[k];
-    RC(check_io(c, &ios[k], true));
-    if (!c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: moment arenas must be bound");
+    RC(check_io(c, &ios[k], what == 0));
+    if (what == 0 && (!c->M || !c->V)) return eae_set_error(EAE_ERR_STATE, "adam: moment arenas must be bound");
     if (c->prof_on || c->fp8 || c->dp_comm || !c->use_gates || c->use_side != c0->use_side || c->nx != c0->nx)
-      return eae_set_error(EAE_ERR_STATE, "group_train_step: members must share device and stream layout, with profiling, fp8 and data parallel off");
-    for (int j = 0; j < k; ++j) if (ctxs[j] == c) return eae_set_error(EAE_ERR_ARG, "group_train_step: a context appears twice");
+      return eae_set_error(EAE_ERR_STATE, "group call: members must share the stream layout, with profiling, fp8 and data parallel off");
+    for (int j = 0; j < k; ++j) if (ctxs[j] == c) return eae_set_error(EAE_ERR_ARG, "group call: a context appears twice");
   }
   static thread_local std::vector<GroupRec> recs;
   if ((int)recs.size() < n) recs.resize(n);
-  static const bool timing = getenv("EAE_GROUP_TIMING") != nullptr;      // diagnostic: host microseconds of the three phases, every 100th call
+  static const bool timing = getenv("EAE_GROUP_TIMING") != nullptr;      // diagnostic: host microseconds of the phases, every 100th call
   static thread_local double t_acc[3] = {0, 0, 0};
   static thread_local int t_n = 0;
   const auto tp0 = std::chrono::steady_clock::now();
   // (recording a member costs ~3 us of host time -- the step logic without its launches; a thread pool that recorded the members side
   //  by side was measured slower than this loop: waking a worker costs more than the work it takes)
   const int mult0 = eae_geo_mult;
-  eae_geo_mult = n;
+  eae_geo_mult = mult;
   for (int k = 0; k < n; ++k) {
     GroupRec& r = recs[k];
     r.clear();
     r.ctx = ctxs[k]; r.user = user; r.slot_of = &group_slot_of;
     eae_rec = &r;
-    const int rc = train_step_eager(ctxs[k], user, &ios[k], lrs[k]);
+    const int rc = what == 0 ? train_step_eager(ctxs[k], user, &ios[k], lrs[k]) : forward_impl(ctxs[k], user, &ios[k], false);
     eae_rec = nullptr;
     if (rc && !r.error) r.error = rc;
     if (r.error) r.msg = eae_last_error();
@@ -1595,13 +1599,13 @@ extern "C" int eae_group_train_step(eae_ctx* const* ctxs, int n, void* stream, c
   // zip
   const size_t len = recs[0].items.size();
   for (int k = 1; k < n; ++k) {
-    if (recs[k].items.size() != len) return eae_set_error(EAE_ERR_STATE, "group_train_step: the members' steps differ in length (different shapes or state)");
+    if (recs[k].items.size() != len) return eae_set_error(EAE_ERR_STATE, "group call: the members' launch sequences differ in length (different shapes or state)");
     for (size_t i = 0; i < len; ++i) {
       const GroupItem& a = recs[0].items[i];
       const GroupItem& b = recs[k].items[i];
       if (a.kind != b.kind || a.slot != b.slot || a.kg != b.kg || (a.kind == GroupItem::LAUNCH &&
           (a.grid.x != b.grid.x || a.grid.y != b.grid.y || a.grid.z != b.grid.z || a.block.x != b.block.x || a.smem != b.smem || a.arg_size != b.arg_size)))
-        return eae_set_error(EAE_ERR_STATE, "group_train_step: the members' steps differ (different shapes or state)");
+        return eae_set_error(EAE_ERR_STATE, "group call: the members' launch sequences differ (different shapes or state)");
     }
   }
   const auto tp2 = std::chrono::steady_clock::now();
@@ -1612,12 +1616,12 @@ extern "C" int eae_group_train_step(eae_ctx* const* ctxs, int n, void* stream, c
     switch (a.kind) {
       case GroupItem::LAUNCH:
         for (int k = 0; k < n; ++k) argv[k] = recs[k].argbuf.data() + recs[k].items[i].arg_off;
-        if (a.fn(a.kg, a.grid, a.block, a.smem, st, argv, n)) return eae_set_error(EAE_ERR_HIP, "group_train_step: a grouped launch failed");
+        if (a.fn(a.kg, a.grid, a.block, a.smem, st, argv, n)) return eae_set_error(EAE_ERR_HIP, "group call: a grouped launch failed");
         break;
       case GroupItem::EV_RECORD: EAE_HIP(hipEventRecord(a.ev, st)); break;
       case GroupItem::EV_WAIT: EAE_HIP(hipStreamWaitEvent(st, a.ev, 0)); break;
       case GroupItem::OP:
-        for (int k = 0; k < n; ++k) if (int e = recs[k].items[i].op(st)) return eae_set_error(EAE_ERR_HIP, "group_train_step: a copy / memset failed"), e;
+        for (int k = 0; k < n; ++k) if (int e = recs[k].items[i].op(st)) return eae_set_error(EAE_ERR_HIP, "group call: a copy / memset failed"), e;
         break;
     }
   }
@@ -1632,6 +1636,14 @@ extern "C" int eae_group_train_step(eae_ctx* const* ctxs, int n, void* stream, c
     }
   }
   return 0;
+}
+}  // namespace
+
+extern "C" int eae_group_train_step(eae_ctx* const* ctxs, int n, int geometry_mult, void* stream, const eae_step_io* ios, const float* lrs) {
+  return group_run(0, ctxs, n, geometry_mult, stream, ios, lrs);
+}
+extern "C" int eae_group_forward(eae_ctx* const* ctxs, int n, int geometry_mult, void* stream, const eae_step_io* ios) {
+  return group_run(1, ctxs, n, geometry_mult, stream, ios, nullptr);
 }
 
 extern "C" int eae_encoder_forward(eae_ctx* c, void* stream, const float* x, int B, int train, float* z) {

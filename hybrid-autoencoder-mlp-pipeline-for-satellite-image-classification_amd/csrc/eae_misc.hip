@@ -63,17 +63,20 @@ __global__ EAE_NO_PK __launch_bounds__(256) void bn_finalize_kernel(const float*
 }
 
 // eval mode: coefficients from the running statistics
-__global__ EAE_NO_PK void bn_eval_coef_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
-                                    float* coef) {
+struct BnEvalCoefArgs { int C; const float* gamma; const float* beta; const float* rm; const float* rv; float eps; float* coef; };
+__device__ __forceinline__ EAE_NO_PK void bn_eval_coef_body(const BnEvalCoefArgs& a) {
+  const int C = a.C;
   int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= C) return;
-  float invstd = 1.0f / sqrtf(rv[ch] + eps);
-  float s = gamma[ch] * invstd;
-  coef[ch] = s;
-  coef[C + ch] = beta[ch] - rm[ch] * s;
-  coef[2 * C + ch] = rm[ch];
-  coef[3 * C + ch] = invstd;
+  float invstd = 1.0f / sqrtf(a.rv[ch] + a.eps);
+  float s = a.gamma[ch] * invstd;
+  a.coef[ch] = s;
+  a.coef[C + ch] = a.beta[ch] - a.rm[ch] * s;
+  a.coef[2 * C + ch] = a.rm[ch];
+  a.coef[3 * C + ch] = invstd;
 }
+__global__ EAE_NO_PK void bn_eval_coef_kernel(BnEvalCoefArgs a) { bn_eval_coef_body(a); }
+__global__ EAE_NO_PK void bn_eval_coef_kernel_g(GroupPack<BnEvalCoefArgs> p, int gz) { bn_eval_coef_body(group_args<BnEvalCoefArgs>(gz)); }
 
 // BatchNorm backward finalize.  part = [2][C][ntiles] (sum g, sum g*xhat), g = ReLU-masked upstream gradient.
 //   dbeta = sum g ; dgamma = sum g*xhat ;  dy = A*g + B*y + Cc  with
@@ -150,8 +153,8 @@ int eae_launch_bn_finalize(hipStream_t st, const float* part, int ntiles, int C,
 }
 int eae_launch_bn_eval_coef(hipStream_t st, int C, const float* gamma, const float* beta, const float* rm, const float* rv,
                             float eps, float* coef) {
-  EAE_NO_GROUP("bn_eval_coef_kernel");
-  hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, C, gamma, beta, rm, rv, eps, coef);
+  const BnEvalCoefArgs ba = {C, gamma, beta, rm, rv, eps, coef};
+  eae_launch(bn_eval_coef_kernel, bn_eval_coef_kernel_g, dim3((C + 63) / 64), dim3(64), 0, st, ba);
   EAE_LAUNCH_CHECK();
   return 0;
 }

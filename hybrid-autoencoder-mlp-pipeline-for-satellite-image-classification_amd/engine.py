@@ -276,24 +276,39 @@ class AEEngine:
         check(self.lib.eae_ae_train_step(self.ctx, _stream(), C.byref(io), float(lr)))
 
     @staticmethod
-    def group_train_step(engines, xs, labels, alphas, lrs, head=True):
+    def _group_ios(engines, xs, labels, alphas, train, head, accum=True):
+        n = len(engines)
+        e0 = engines[0]
+        if any(e.device != e0.device for e in engines):
+            raise RuntimeError("group call: the engines must live on one device")
+        ios = (EaeStepIO * n)()
+        keep = []
+        for k, e in enumerate(engines):
+            io, kp = e._io(xs[k], labels[k], train, head, alphas[k], accum=accum)
+            ios[k] = io
+            keep.append(kp)
+        return ios, (C.c_void_p * n)(*[e.ctx for e in engines]), keep
+
+    @staticmethod
+    def group_train_step(engines, xs, labels, alphas, lrs, head=True, geometry_mult=0):
         """One iteration of the batch loop for SEVERAL configurations of the grid at once (R.md:599-711: same architecture, own
         alpha / lr / parameters / batches): include/eae.h eae_group_train_step -- one sequence of grouped launches instead of one per
         engine.  engines: same shape, same device; xs / labels: one batch each (same batch size)."""
         n = len(engines)
-        e0 = engines[0]
-        if any(e.device != e0.device for e in engines):
-            raise RuntimeError("group_train_step: the engines must live on one device")
-        ios = (EaeStepIO * n)()
-        keep = []
-        for k, e in enumerate(engines):
-            io, kp = e._io(xs[k], labels[k], True, head, alphas[k])
-            ios[k] = io
-            keep.append(kp)
-        ctxs = (C.c_void_p * n)(*[e.ctx for e in engines])
+        ios, ctxs, keep = AEEngine._group_ios(engines, xs, labels, alphas, True, head)
         lr_arr = (C.c_float * n)(*[float(v) for v in lrs])
+        e0 = engines[0]
         with torch.cuda.device(e0.device):
-            check(e0.lib.eae_group_train_step(ctxs, n, _stream(), ios, lr_arr))
+            check(e0.lib.eae_group_train_step(ctxs, n, int(geometry_mult), _stream(), ios, lr_arr))
+
+    @staticmethod
+    def group_eval_step(engines, xs, labels, alphas, head=True, geometry_mult=0):
+        """The validation pass of the same configurations (R.md:670-682): eval-mode forward + loss, accumulated on the device."""
+        n = len(engines)
+        ios, ctxs, keep = AEEngine._group_ios(engines, xs, labels, alphas, False, head)
+        e0 = engines[0]
+        with torch.cuda.device(e0.device):
+            check(e0.lib.eae_group_forward(ctxs, n, int(geometry_mult), _stream(), ios))
 
     @_on_device
     def encoder(self, x, train=False):

@@ -53,6 +53,47 @@ class AEStepper:
         return loss, n
 
 
+class GroupAEStepper:
+    """Stepper for SEVERAL SupervisedAutoencoder configurations trained in lockstep on the same batches (the grid of R.md:599-711):
+    every step of the still-active members is ONE sequence of grouped launches (engine.AEEngine.group_train_step / group_eval_step,
+    include/eae.h eae_group_train_step).  `active` = indices of the members that have not stopped early; the tile geometries stay
+    those of the full group, so a member's arithmetic does not depend on which other members are still training."""
+
+    def __init__(self, models, alphas, lrs, head=True, max_batch=None):
+        from .engine import engine_for
+        self.models, self.alphas, self.lrs, self.head = list(models), [float(a) for a in alphas], [float(v) for v in lrs], head
+        self.engs = [engine_for(m, max_batch=max_batch) for m in self.models]
+        for e in self.engs:
+            e.reset_optimizer()
+        self.mult = len(self.engs)
+        self.device = self.engs[0].device
+
+    def _pick(self, active):
+        return [self.engs[k] for k in active], [self.alphas[k] for k in active], [self.lrs[k] for k in active]
+
+    def begin(self, active):
+        for k in active:
+            self.engs[k].reset_loss()
+
+    def train_step(self, imgs, labels, active):
+        from .engine import AEEngine
+        engs, alphas, lrs = self._pick(active)
+        AEEngine.group_train_step(engs, [imgs] * len(engs), [labels] * len(engs), alphas, lrs, head=self.head, geometry_mult=self.mult)
+
+    def eval_step(self, imgs, labels, active):
+        from .engine import AEEngine
+        engs, alphas, _ = self._pick(active)
+        AEEngine.group_eval_step(engs, [imgs] * len(engs), [labels] * len(engs), alphas, head=self.head, geometry_mult=self.mult)
+
+    def end(self, active):
+        out = []
+        for k in active:
+            loss, _, _, n, _ = self.engs[k].read_loss()
+            self.engs[k].check_gates(sync=False)
+            out.append((loss, n))
+        return out
+
+
 class MLPStepper:
     def __init__(self, clf, lr, weight_decay=1e-4, max_batch=None):
         from .mlp_engine import mlp_engine_for
@@ -135,6 +176,67 @@ def fit_autoencoder(train_loader, val_loader, alpha, lr, latent_dim=64, num_clas
             "epochs": len(train_curve)}
 
 
+def fit_autoencoder_group(train_loader, val_loader, configs, latent_dim=64, num_classes=10, num_epochs=80, patience=15,
+                          device="cuda", models=None, stepper=None, head=True, verbose=True, logs=None):
+    """fit_autoencoder for SEVERAL (alpha, lr) configurations at once: the members share every batch of the two loaders (one pass of
+    the loader per epoch for the whole group) and each keeps its own curves, best loss and early-stopping counter exactly as the
+    reference's loop does for it alone (R.md:619-697); a member that stops early drops out, the others go on.
+
+    Returns one fit_autoencoder-style dict per configuration.  logs: optional list of per-configuration line lists."""
+    n = len(configs)
+    if models is None and stepper is None:
+        models = [SupervisedAutoencoder(latent_dim=latent_dim, num_classes=num_classes).to(device) for _ in range(n)]
+    if stepper is None:
+        stepper = GroupAEStepper(models, [a for a, _ in configs], [l for _, l in configs], head=head,
+                                 max_batch=max(_first_batch_size(train_loader), _first_batch_size(val_loader)))
+    dev = getattr(stepper, "device", None)
+    lines = logs if logs is not None else [[] for _ in range(n)]
+    counter, best = [0] * n, [float("inf")] * n
+    train_curve, val_curve = [[] for _ in range(n)], [[] for _ in range(n)]
+    active = list(range(n))
+    for epoch in range(num_epochs):
+        if not active:
+            break
+        if models is not None:
+            for k in active:
+                models[k].train()
+        stepper.begin(active)
+        for imgs, labels in train_loader:
+            if dev is not None:
+                imgs, labels = _to(imgs, dev), _to(labels, dev)
+            stepper.train_step(imgs, labels, active)
+        tr = stepper.end(active)
+        if models is not None:
+            for k in active:
+                models[k].eval()
+        stepper.begin(active)
+        with torch.no_grad():
+            for imgs, labels in val_loader:
+                if dev is not None:
+                    imgs, labels = _to(imgs, dev), _to(labels, dev)
+                stepper.eval_step(imgs, labels, active)
+        va = stepper.end(active)
+        still = []
+        for j, k in enumerate(active):
+            alpha, lr = configs[k]
+            train_curve[k].append(tr[j][0]); val_curve[k].append(va[j][0])
+            if verbose:
+                lines[k].append(f"[AE α={alpha} LR={lr}] Epoch {epoch + 1} | TrainLoss={tr[j][0]:.4f} | ValLoss={va[j][0]:.4f}")
+            if va[j][0] < best[k]:            # strict improvement, R.md:690
+                best[k] = va[j][0]; counter[k] = 0
+                still.append(k)
+            else:
+                counter[k] += 1
+                if counter[k] >= patience:
+                    if verbose:
+                        lines[k].append("Early stopping triggered.")
+                else:
+                    still.append(k)
+        active = still
+    return [{"model": None if models is None else models[k], "train_curve": train_curve[k], "val_curve": val_curve[k],
+             "best_val_loss": best[k], "epochs": len(train_curve[k])} for k in range(n)]
+
+
 def run_concurrent(jobs, concurrent, device="cuda"):
     """Run `jobs` (callables without arguments) on `concurrent` host threads, each with its OWN HIP stream current
     (torch.cuda.stream is thread-local), and return their results in job order.  This is how several small configurations share one
@@ -164,7 +266,8 @@ def run_concurrent(jobs, concurrent, device="cuda"):
 
 def grid_search_autoencoder(train_loader, val_loader, alpha_values=(20, 25, 30, 35, 40),
                             lr_values=(1e-4, 2e-4, 5e-4, 1e-3, 2e-3, 5e-3, 1e-2, 5e-2, 1e-1), latent_dim=64, num_epochs=80,
-                            patience=15, out_dir="models_best", device="cuda", verbose=True, log=print, fit_fn=None, concurrent=1):
+                            patience=15, out_dir="models_best", device="cuda", verbose=True, log=print, fit_fn=None, concurrent=1,
+                            grouped=0, group_fit_fn=None):
     """The reference's alpha x lr grid (R.md:599-729): trains every configuration, keeps the global best, writes
     `out_dir/AE_GLOBAL_BEST.pt` (plain state_dict) and `out_dir/validation_losses.json` (keys "alpha={a}, lr={lr}").
 
@@ -175,13 +278,33 @@ def grid_search_autoencoder(train_loader, val_loader, alpha_values=(20, 25, 30, 
     depend on torch's global generator (a shuffling DataLoader draws its per-iterator seed from it, in whatever order the worker
     threads reach it: give such a loader its own `generator=`); a custom `fit_fn` that builds its own model has to seed it itself
     (tests/test_gpu_grid.py covers both).  The log lines of a configuration are emitted together, in grid order, and the global
-    best is chosen in grid order with the reference's strict `<` -- the same winner as the sequential loop."""
+    best is chosen in grid order with the reference's strict `<` -- the same winner as the sequential loop.
+
+    grouped=K > 1 (takes precedence) trains the grid K configurations at a time IN LOCKSTEP (fit_autoencoder_group): the K members step
+    on the same batches with ONE sequence of grouped launches per step -- at the reference's batch size 64 that is what fills the GPU
+    (bench.py `configs.grid_b64`) -- and the loaders are walked once per epoch for the whole group.  Each
+    member's arithmetic is bitwise that of the configuration trained alone on the same batches with the group's tile geometries
+    (tests/test_gpu_grid.py); what differs from the sequential grid is the data order when the loader shuffles: the members of a
+    group see the same permutation per epoch instead of consecutive draws from the generator."""
     os.makedirs(out_dir, exist_ok=True)
     fit_fn = fit_fn or fit_autoencoder
     results, best = {}, {"loss": float("inf"), "info": None, "state": None, "train": None, "val": None}
     grid = [(alpha, lr) for alpha in alpha_values for lr in lr_values]
     fitted = None
-    if concurrent and int(concurrent) > 1:
+    if grouped and int(grouped) > 1:
+        gfit = group_fit_fn or fit_autoencoder_group
+        fitted = []
+        for g0 in range(0, len(grid), int(grouped)):
+            cfgs = grid[g0:g0 + int(grouped)]
+            lines = [[] for _ in cfgs]
+            rs = gfit(train_loader, val_loader, cfgs, latent_dim=latent_dim, num_epochs=num_epochs, patience=patience, device=device,
+                      verbose=verbose, logs=lines)
+            for r, ln in zip(rs, lines):
+                r = dict(r)
+                r["state"] = None if r.get("model") is None else {k: v.detach().cpu().clone() for k, v in r["model"].state_dict().items()}
+                r["model"] = None           # release the engine (workspace, streams) of a finished configuration
+                fitted.append((r, ln))
+    elif concurrent and int(concurrent) > 1:
         # parameter initialisation draws from torch's global generator: K worker threads would draw in timing-dependent order (ADVICE r3)
         prebuilt = {}
         if fit_fn is fit_autoencoder:

@@ -186,15 +186,19 @@ int eae_set_sync_bn(eae_ctx* ctx, int world, eae_sync_fn fn, void* user, void* a
 /* eae_ae_grad_step + eae_adam_step: one iteration of the reference's batch loop (R.md:642-658). */
 int eae_ae_train_step(eae_ctx* ctx, void* stream, const eae_step_io* io, float lr);
 /* The grid of independent configurations the reference trains one after the other at batch 64 (R.md:246, 599-711), n of them per
- * call: eae_ae_train_step's eager path for ctxs[0..n) -- each with its own io block (inputs, labels, alpha, outputs) and lr -- enqueued as
- * ONE sequence of grouped launches on `stream` and ctxs[0]'s side streams (workgroup z of every launch works for member z with that
- * member's own arguments).  Each member's results are bitwise what eae_ae_train_step gives it alone with the same tile geometries
- * (eae_set_geometry_mult(n)).  The members must have the same configuration, batch size and requested outputs, live on the current
- * device, and have profiling, fp8 and data parallel off; a mismatch is an error and leaves the members' host-side state advanced
- * (as a failed step does).  n <= 64; launches carry 8 members at a time. */
-int eae_group_train_step(eae_ctx* const* ctxs, int n, void* stream, const eae_step_io* ios, const float* lrs);
+ * call: eae_ae_train_step's eager path (eae_group_train_step) or eae_ae_forward (eae_group_forward: the validation pass, R.md:670-682)
+ * for ctxs[0..n) -- each with its own io block (inputs, labels, alpha, outputs) and lr -- enqueued as ONE sequence of grouped launches
+ * on `stream` and ctxs[0]'s side streams (workgroup z of every launch works for member z with that member's own arguments).
+ * geometry_mult: the launchers choose tile geometries and grids as for a batch of B * geometry_mult (0 = n; a caller whose group
+ * shrinks -- early stopping -- keeps passing the original size so that a member's arithmetic does not depend on who else is still
+ * training).  Each member's results are bitwise what the single-context call gives it under eae_set_geometry_mult(geometry_mult).
+ * The members must have the same configuration, batch size and requested outputs, live on the current device, and have profiling,
+ * fp8 and data parallel off; a mismatch is an error and leaves the members' host-side state advanced (as a failed step does).
+ * n <= 64; launches carry 8 members at a time. */
+int eae_group_train_step(eae_ctx* const* ctxs, int n, int geometry_mult, void* stream, const eae_step_io* ios, const float* lrs);
+int eae_group_forward(eae_ctx* const* ctxs, int n, int geometry_mult, void* stream, const eae_step_io* ios);
 /* Thread-local: launchers that choose a tile geometry or a grid by the size of the batch see batch * mult (1 = default).  Used by the
- * group-vs-alone parity test; eae_group_train_step sets it to n for its own duration. */
+ * group-vs-alone parity tests; the group calls set it to their geometry_mult for their own duration. */
 int eae_set_geometry_mult(int mult);
 /* Encoder alone in the current mode (extract_features, R.md:2504: z = encoder(imgs)). */
 int eae_encoder_forward(eae_ctx* ctx, void* stream, const float* x, int B, int train, float* z);

@@ -146,3 +146,32 @@ def test_single_stream_context_is_bitwise_the_default_one(b):
         for k in a[3]:
             assert np.array_equal(a[3][k], c[3][k]), k
     assert np.isfinite(a[0]).all() and np.abs(a[1]).max() > 0
+
+
+def test_grouped_grid_is_bitwise_the_sequential_one_with_the_groups_geometries(tmp_path):
+    """grid_search_autoencoder(grouped=4): four configurations step in lockstep through ONE sequence of grouped launches per batch
+    (include/eae.h eae_group_train_step / eae_group_forward).  Under torch.manual_seed the default model construction draws the same
+    parameters in grid order as the sequential grid, and with the sequential run's launchers set to the group's tile geometries
+    (eae_set_geometry_mult(4)) every configuration's curves, early-stopping epoch and the saved winner are bitwise equal.
+    patience=1: members drop out of the group at different epochs, the others go on with unchanged arithmetic."""
+    from eae_amd import _lib
+    from eae_amd import train as T
+    lib = _lib.load()
+    tr, va = _loaders()
+    kw = dict(alpha_values=(20, 35), lr_values=(1e-3, 2e-2), num_epochs=4, patience=1, verbose=True)
+    seq_log, grp_log = [], []
+    torch.manual_seed(4242)
+    _lib.check(lib.eae_set_geometry_mult(4))
+    try:
+        seq = T.grid_search_autoencoder(tr, va, out_dir=str(tmp_path / "seq"), log=seq_log.append, **kw)
+    finally:
+        _lib.check(lib.eae_set_geometry_mult(1))
+    torch.manual_seed(4242)
+    grp = T.grid_search_autoencoder(tr, va, out_dir=str(tmp_path / "grp"), grouped=4, log=grp_log.append, **kw)
+    assert seq["results"] == grp["results"], (seq["results"], grp["results"])
+    assert (seq["best_alpha"], seq["best_lr"]) == (grp["best_alpha"], grp["best_lr"])
+    assert seq["best_train_curve"] == grp["best_train_curve"] and seq["best_val_curve"] == grp["best_val_curve"]
+    assert seq_log == grp_log
+    assert all(np.isfinite(v) for v in seq["results"].values())
+    sa, sb = torch.load(seq["best_path"]), torch.load(grp["best_path"])
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)

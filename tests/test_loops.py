@@ -96,6 +96,85 @@ def test_grid_search_concurrent_same_bookkeeping_and_log_order(tmp_path):
     assert json.load(open(tmp_path / "k4" / "validation_losses.json")) == json.load(open(tmp_path / "k1" / "validation_losses.json"))
 
 
+class ScriptedGroup:
+    """K scripted members behind the group-stepper interface (begin / train_step / eval_step / end with the active index list)."""
+    device = None
+
+    def __init__(self, members):
+        self.m = members
+        self.calls = []
+
+    def begin(self, active):
+        for k in active:
+            self.m[k].begin()
+
+    def train_step(self, x, y, active):
+        self.calls.append(("t", len(x), tuple(active)))
+        for k in active:
+            self.m[k].train_step(x, y)
+
+    def eval_step(self, x, y, active):
+        self.calls.append(("v", len(x), tuple(active)))
+        for k in active:
+            self.m[k].eval_step(x, y)
+
+    def end(self, active):
+        return [self.m[k].end() for k in active]
+
+
+def test_group_fit_is_the_sequential_fit_per_member_and_drops_stopped_members():
+    """fit_autoencoder_group keeps every member's curves / best / early stopping exactly as fit_autoencoder does for it alone
+    (R.md:686-697), walks the loaders once per epoch for the whole group, and stops stepping a member once it has stopped."""
+    vals = [[5.0, 4.0, 4.0, 4.5, 4.2, 3.0, 1.0], [3.0, 3.5, 3.6, 3.7, 1.0, 1.0, 1.0], [9.0, 8.0, 7.0, 6.0, 5.0, 4.0, 3.0]]
+    trains = [[9, 8, 7, 6, 5, 4, 3], [1, 1, 1, 1, 1, 1, 1], [2, 2, 2, 2, 2, 2, 2]]
+    cfgs = [(35, 1e-3), (20, 2e-3), (40, 5e-3)]
+    alone, alone_logs = [], []
+    for k in range(3):
+        lg = []
+        alone.append(T.fit_autoencoder(_loader([64, 48]), _loader([64, 56]), alpha=cfgs[k][0], lr=cfgs[k][1], num_epochs=7, patience=3,
+                                       stepper=ScriptedAE(trains[k], vals[k]), model=None, log=lg.append))
+        alone_logs.append(lg)
+    st = ScriptedGroup([ScriptedAE(trains[k], vals[k]) for k in range(3)])
+    lines = [[] for _ in range(3)]
+    rs = T.fit_autoencoder_group(_loader([64, 48]), _loader([64, 56]), cfgs, num_epochs=7, patience=3, stepper=st, models=None, logs=lines)
+    for k in range(3):
+        for key in ("train_curve", "val_curve", "best_val_loss", "epochs"):
+            assert rs[k][key] == alone[k][key], (k, key)
+        assert lines[k] == alone_logs[k]
+    assert [r["epochs"] for r in rs] == [5, 4, 7]
+    # epoch 1: all three members on every batch; epoch 5: member 1 (stopped after 4) is no longer stepped; epoch 6: member 0 gone too
+    assert st.calls[:4] == [("t", 64, (0, 1, 2)), ("t", 48, (0, 1, 2)), ("v", 64, (0, 1, 2)), ("v", 56, (0, 1, 2))]
+    assert st.calls[16] == ("t", 64, (0, 2)) and st.calls[20] == ("t", 64, (2,))
+
+
+def test_grid_search_grouped_same_bookkeeping_and_log_order(tmp_path):
+    """grouped=K: the grid is cut into groups of K in grid order, results / JSON / winner / log order are those of the sequential grid."""
+    table = {(20, 0.1): 3.0, (20, 0.2): 2.5, (30, 0.1): 2.5, (30, 0.2): 2.7, (40, 0.1): 2.4, (40, 0.2): 2.4}
+    seen = []
+
+    def fake_fit(tr, va, alpha, lr, log=print, **kw):
+        log(f"fit {alpha} {lr}")
+        return {"model": None, "train_curve": [1.0], "val_curve": [table[(alpha, lr)]], "best_val_loss": table[(alpha, lr)], "epochs": 1}
+
+    def fake_group_fit(tr, va, cfgs, logs=None, **kw):
+        seen.append(list(cfgs))
+        out = []
+        for k, (a, lr) in enumerate(cfgs):
+            logs[k].append(f"fit {a} {lr}")
+            out.append({"model": None, "train_curve": [1.0], "val_curve": [table[(a, lr)]], "best_val_loss": table[(a, lr)], "epochs": 1})
+        return out
+
+    seq_logs, grp_logs = [], []
+    a = T.grid_search_autoencoder(None, None, alpha_values=(20, 30, 40), lr_values=(0.1, 0.2), out_dir=str(tmp_path / "seq"), fit_fn=fake_fit,
+                                  log=seq_logs.append)
+    b = T.grid_search_autoencoder(None, None, alpha_values=(20, 30, 40), lr_values=(0.1, 0.2), out_dir=str(tmp_path / "grp"), grouped=4,
+                                  group_fit_fn=fake_group_fit, log=grp_logs.append)
+    assert seen == [[(20, 0.1), (20, 0.2), (30, 0.1), (30, 0.2)], [(40, 0.1), (40, 0.2)]]
+    assert a["results"] == b["results"] and (a["best_alpha"], a["best_lr"]) == (b["best_alpha"], b["best_lr"]) == (40, 0.1)
+    assert seq_logs == grp_logs
+    assert json.load(open(tmp_path / "seq" / "validation_losses.json")) == json.load(open(tmp_path / "grp" / "validation_losses.json"))
+
+
 class ScriptedMLP:
     device = None
 
