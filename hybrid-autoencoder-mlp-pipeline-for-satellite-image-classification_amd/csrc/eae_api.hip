@@ -107,6 +107,8 @@ struct eae_ctx {
   uint8_t* pack = nullptr;
   PackDesc* descs_dev = nullptr;
   int ndesc = 0;
+  unsigned short* blkmap = nullptr;   // flattened pack launch (eae_pack_assign_blocks): workgroup -> descriptor; blk_tot workgroups, the first blk_late belong to descriptors 0..ndesc_late-1
+  int blk_tot = 0, blk_late = 0;
   size_t pk_c1, pk_p1[6], pk_p2[6], pk_d4j, pk_d4k, pk_we1, pk_we2, pk_wd1, pk_wd2, pk_bd;
   // second stream: weight-gradient kernels, the classifier head and the slice reductions do not sit on the
   // forward / backward-data dependency chain, so they run concurrently with it (fork/join through events)
@@ -340,7 +342,11 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->ndesc_late = 0;
   while (c->ndesc_late < c->ndesc && descs[c->ndesc_late].src_off < c->poff[8]) c->ndesc_late++;
   for (int k = c->ndesc_late; k < c->ndesc; ++k) if (descs[k].src_off < c->poff[8]) c->ndesc_late = -1;      // (not a prefix: no split)
+  std::vector<unsigned short> blkmap(descs.size() * 1024);
+  c->blk_tot = eae_pack_assign_blocks(descs.data(), (int)descs.size(), blkmap.data(), (int)blkmap.size());
+  c->blk_late = c->ndesc_late > 0 ? descs[c->ndesc_late - 1].blk0 + descs[c->ndesc_late - 1].nblk : 0;
   size_t o_pack = carve(poffb), o_desc = carve(descs.size() * sizeof(PackDesc)), o_q = carve(sizeof(Fp8State)), o_bns = carve(2048 * 4 + 64);
+  size_t o_bmap = carve((size_t)(c->blk_tot > 0 ? c->blk_tot : 1) * sizeof(unsigned short));
   hipError_t e = hipMalloc(&c->ws, off);
   if (e != hipSuccess) { delete c; return eae_set_error(EAE_ERR_HIP, hipGetErrorString(e)); }
   uint8_t* b = static_cast<uint8_t*>(c->ws);
@@ -364,7 +370,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   for (int l = 0; l < 7; ++l) c->accb[l] = (unsigned long long*)(b + o_accb + acc_total + o_acc[l]);
   for (int i = 0; i < c->nx; ++i) c->wscratchx[i] = (float*)(b + o_wscrx[i]); c->fcpart = (float*)(b + o_fcp);
   c->msepart = (float*)(b + o_mse); c->cepart = (float*)(b + o_ce); c->headpart = (float*)(b + o_head); c->lossbuf = (float*)(b + o_loss);
-  c->pack = b + o_pack; c->descs_dev = (PackDesc*)(b + o_desc);
+  c->pack = b + o_pack; c->descs_dev = (PackDesc*)(b + o_desc); c->blkmap = (unsigned short*)(b + o_bmap);
   c->dyn = (float*)(b + o_dyn);
   c->sigwords = (unsigned*)(b + o_sig);
   c->q = (Fp8State*)(b + o_q);
@@ -384,6 +390,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   // (0.80 ms/step) while the eager two-stream launch sequence overlaps them (0.71 ms/step)
   c->use_graph = getenv("EAE_GRAPH") != nullptr && getenv("EAE_NO_GRAPH") == nullptr;
   e = hipMemcpy(c->descs_dev, descs.data(), descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
+  if (e == hipSuccess && c->blk_tot > 0) e = hipMemcpy(c->blkmap, blkmap.data(), (size_t)c->blk_tot * sizeof(unsigned short), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(c->g4, 0, Bm * (size_t)c->H * c->W * 4 * 2);
   if (e == hipSuccess && c->lpad) e = hipMemset(c->zstage, 0, Bm * (size_t)c->Lp * 4);
   if (e == hipSuccess) e = hipMemset(c->z, 0, Bm * (size_t)c->Lp * 4);
@@ -716,6 +723,10 @@ int ensure_packed(eae_ctx* c, hipStream_t st) {
   // (the pack kernel also clears the step-wide non-finite word: the optimizer kernel that clears the accumulators READS that word)
   // (the four latent-projection packs are 96 % of the elements at 256x256 inputs -- 16.7 M each: four times the workgroups there)
   static const int pack_blocks_big = getenv("EAE_PACK_BLOCKS") ? atoi(getenv("EAE_PACK_BLOCKS")) : 1024;
+  // EAE_PACK_FLAT=0: the 2-D launch of rounds 1-4 (the same number of workgroups for every descriptor; A/B switch)
+  static const bool flat = !(getenv("EAE_PACK_FLAT") && atoi(getenv("EAE_PACK_FLAT")) == 0);
+  if (flat && c->blk_tot > 0) RC(eae_launch_pack_flat(st, c->descs_dev, c->blkmap, 0, c->blk_tot, c->P, c->pack, c->fp8 ? c->q : nullptr, poison_word(c)));
+  else
   RC(eae_launch_pack_all(st, c->descs_dev, c->ndesc, c->P, c->pack, c->fp8 ? c->q : nullptr, poison_word(c),
                          (long long)c->K * c->Lp >= (1LL << 22) ? pack_blocks_big : 256));
   c->packed = true;

@@ -13,6 +13,9 @@ struct PackDesc {
   int out_f32;         // 1: destination is fp32 (permuted biases), 0: bf16
   int lv;              // FC modes / PACK_PAD_COLS: number of REAL entries along the latent dimension d0 (the rest of d0 is zero padding)
   int q_layer;         // >= 0: destination is e4m3 bytes scaled by the weight scale of 3x3 layer q_layer (fp8 variant, Fp8State below)
+  // flattened launch (eae_pack_assign_blocks): the descriptor owns workgroups [blk0, blk0 + nblk) of the list it belongs to, nblk
+  // proportional to its work; 0 / 0 = the 2-D launch (blocks_per_desc workgroups for every descriptor)
+  int blk0, nblk;
 };
 
 // fp8 variant (BASELINE config 5) -- delayed scaling state in device memory, one per context.  Index i = 3x3 layer in W3 order
@@ -64,6 +67,11 @@ int eae_launch_signal(hipStream_t st, unsigned* word, unsigned val);
 // blocks_per_desc: workgroups per descriptor (grid.x; every descriptor loops over its elements / tiles with that stride)
 int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base, Fp8State* q = nullptr, unsigned* clear_word = nullptr,
                         int blocks_per_desc = 256);
+// Flattened form: workgroups [blk_begin, blk_begin + blk_count) of the list `descs_all` (whole list, device) that eae_pack_assign_blocks
+// laid out; blkmap[b] (device) = index of the descriptor that owns workgroup b.
+int eae_pack_assign_blocks(PackDesc* descs_host, int ndesc, unsigned short* blkmap_host, int blkmap_cap);      // returns the total, fills blk0 / nblk / the map
+int eae_launch_pack_flat(hipStream_t st, const PackDesc* descs_all, const unsigned short* blkmap, int blk_begin, int blk_count, const float* params,
+                         void* pack_base, Fp8State* q = nullptr, unsigned* clear_word = nullptr);
 int eae_launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2,
                     double eps, double wd, long long step);
 int eae_launch_adam_dyn(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, double b1, double b2, double eps,

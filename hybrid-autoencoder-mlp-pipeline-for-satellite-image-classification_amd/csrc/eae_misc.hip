@@ -275,18 +275,24 @@ __device__ __forceinline__ float pack_fetch(const PackDesc& d, const float* __re
   }
 }
 
-struct PackAllArgs { const PackDesc* descs; const float* params; uint8_t* pack_base; Fp8State* q; unsigned* clear_word; };
+struct PackAllArgs { const PackDesc* descs; const float* params; uint8_t* pack_base; Fp8State* q; unsigned* clear_word; const unsigned short* blkmap; int blk_begin; };
 __device__ __forceinline__ EAE_NO_PK void pack_all_body(const PackAllArgs& pa) {
   const PackDesc* __restrict__ descs = pa.descs; const float* __restrict__ params = pa.params; uint8_t* __restrict__ pack_base = pa.pack_base;
   Fp8State* __restrict__ q = pa.q; unsigned* __restrict__ clear_word = pa.clear_word;
+  // the workgroup's descriptor and its place among the descriptor's workgroups: 2-D launch (y = descriptor, the same number of
+  // workgroups for each) or flattened (blkmap: a descriptor has as many workgroups as its work needs -- the 2-D form spent most of its
+  // workgroups on the ~20 small descriptors while a handful looped over the four 262 K-element projections)
+  const bool flat = pa.blkmap != nullptr;
+  const unsigned gb = flat ? (unsigned)pa.blk_begin + blockIdx.x : 0u;
+  const PackDesc d = descs[flat ? (unsigned)pa.blkmap[gb] : blockIdx.y];
+  const unsigned bx = flat ? gb - (unsigned)d.blk0 : blockIdx.x, nbx = flat ? (unsigned)d.nblk : gridDim.x;
   if (clear_word != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *clear_word = 0u;
-  const PackDesc d = descs[blockIdx.y];
   const float* src = params + d.src_off;
   const unsigned count = (unsigned)d.count;
   if (d.q_layer >= 0) {        // e4m3 bytes = sat(w * s_w); also reports max |w| for the next step's scale (delayed scaling)
     const float sw = q->s_w[d.q_layer];
     float mx = 0.f;
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+    for (unsigned i = bx * 256u + threadIdx.x; i < count; i += nbx * 256u) {
       const float v = pack_fetch(d, src, i);
       mx = fmaxf(mx, fabsf(v));
       const float sv = fminf(fmaxf(v * sw, -448.f), 448.f);
@@ -294,7 +300,7 @@ __device__ __forceinline__ EAE_NO_PK void pack_all_body(const PackAllArgs& pa) {
     }
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&q->amax_w[d.q_layer][((blockIdx.x * 4 + (threadIdx.x >> 6)) & (FP8_AMAX_SLOTS - 1)) * FP8_AMAX_STRIDE], __float_as_uint(mx));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&q->amax_w[d.q_layer][((bx * 4 + (threadIdx.x >> 6)) & (FP8_AMAX_SLOTS - 1)) * FP8_AMAX_STRIDE], __float_as_uint(mx));
     return;
   }
   if ((d.mode == PACK_3x3_P1 || d.mode == PACK_3x3_P2) && !d.out_f32) {
@@ -304,7 +310,7 @@ __device__ __forceinline__ EAE_NO_PK void pack_all_body(const PackAllArgs& pa) {
     const unsigned A = (unsigned)d.d0, Bq = (unsigned)d.d1;
     const bool p1 = d.mode == PACK_3x3_P1;
     bf16_t* dst = reinterpret_cast<bf16_t*>(pack_base + d.dst_off);
-    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < A * Bq; t += gridDim.x * 256u) {
+    for (unsigned t = bx * 256u + threadIdx.x; t < A * Bq; t += nbx * 256u) {
       const unsigned a = p1 ? t / Bq : t % A, b = p1 ? t % Bq : t / A;
       const float* sp = src + ((size_t)a * Bq + b) * 9;
       float w[9];
@@ -327,7 +333,7 @@ __device__ __forceinline__ EAE_NO_PK void pack_all_body(const PackAllArgs& pa) {
     const unsigned ncc = Cc / 64, nlc = Lp / 64, ntiles = P * ncc * nlc;
     const bool vec = (lv & 3u) == 0;
     bf16_t* dst = reinterpret_cast<bf16_t*>(pack_base + d.dst_off);
-    for (unsigned tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    for (unsigned tl = bx; tl < ntiles; tl += nbx) {
       const unsigned lc = tl % nlc, cch = (tl / nlc) % ncc, p = tl / (nlc * ncc);
       const unsigned c0 = cch * 64, l0 = lc * 64;
       __syncthreads();
@@ -364,7 +370,7 @@ __device__ __forceinline__ EAE_NO_PK void pack_all_body(const PackAllArgs& pa) {
     const bool rowmajor = d.mode == PACK_FC_ROWMAJOR_KPERM;
     const unsigned npc = P / 64, nA = rowmajor ? Cc / 64 : R / 64, nfix = rowmajor ? R : Cc, ntiles = nfix * nA * npc;
     bf16_t* dst = reinterpret_cast<bf16_t*>(pack_base + d.dst_off);
-    for (unsigned tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    for (unsigned tl = bx; tl < ntiles; tl += nbx) {
       const unsigned pc = tl % npc, ac = (tl / npc) % nA, fix = tl / (npc * nA);
       const unsigned p0 = pc * 64, a0 = ac * 64;                 // a = channel (row-major form) or row (transposed form)
       __syncthreads();
@@ -397,7 +403,7 @@ __device__ __forceinline__ EAE_NO_PK void pack_all_body(const PackAllArgs& pa) {
     const unsigned R = (unsigned)d.d0, Cc = (unsigned)d.d1, P = (unsigned)d.d2, K = Cc * P, lv = (unsigned)d.lv;
     const bool rowmajor = d.mode == PACK_FC_ROWMAJOR_KPERM;
     bf16_t* dst = reinterpret_cast<bf16_t*>(pack_base + d.dst_off);
-    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < R * Cc; t += gridDim.x * 256u) {
+    for (unsigned t = bx * 256u + threadIdx.x; t < R * Cc; t += nbx * 256u) {
       const unsigned r = rowmajor ? t / Cc : t % R, c = rowmajor ? t % Cc : t / R;
       const float* sp = src + (size_t)r * K + (size_t)c * P;
       for (unsigned p = 0; p < P; p += 4) {
@@ -417,7 +423,7 @@ __device__ __forceinline__ EAE_NO_PK void pack_all_body(const PackAllArgs& pa) {
     // loads, one 16-byte store) instead of one float in and one bf16 out (16.7 M elements at 256x256 inputs)
     const unsigned Lp = (unsigned)d.d0, Cc = (unsigned)d.d1, P = (unsigned)d.d2, lv = (unsigned)d.lv, n8 = count / 8u, l8n = Lp / 8u;
     bf16_t* dst = reinterpret_cast<bf16_t*>(pack_base + d.dst_off);
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n8; i += gridDim.x * 256u) {
+    for (unsigned i = bx * 256u + threadIdx.x; i < n8; i += nbx * 256u) {
       const unsigned l = (i % l8n) * 8u, j2 = i / l8n, cc = j2 % Cc, pp = j2 / Cc;
       uint4 o = make_uint4(0, 0, 0, 0);
       if (l < lv) {
@@ -429,7 +435,7 @@ __device__ __forceinline__ EAE_NO_PK void pack_all_body(const PackAllArgs& pa) {
     }
     return;
   }
-  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+  for (unsigned i = bx * 256u + threadIdx.x; i < count; i += nbx * 256u) {
     float v = pack_fetch(d, src, i);
     if (d.out_f32) reinterpret_cast<float*>(pack_base + d.dst_off)[i] = v;
     else reinterpret_cast<bf16_t*>(pack_base + d.dst_off)[i] = (bf16_t)f2bf(v);
@@ -440,12 +446,47 @@ __global__ EAE_NO_PK __launch_bounds__(256) void pack_all_kernel_g(GroupPack<Pac
 
 int eae_launch_pack_all(hipStream_t st, const PackDesc* descs_dev, int ndesc, const float* params, void* pack_base, Fp8State* q, unsigned* clear_word,
                         int blocks_per_desc) {
-  const PackAllArgs pa = {descs_dev, params, (uint8_t*)pack_base, q, clear_word};
+  const PackAllArgs pa = {descs_dev, params, (uint8_t*)pack_base, q, clear_word, nullptr, 0};
   if (blocks_per_desc <= 0) blocks_per_desc = 256;
   // member of a grouped step: the launch carries eae_geo_mult members' descriptors (8 x 256 x ~20 workgroups, most of them with a few
   // hundred elements, took 54 us: the dispatch of 41 K workgroups, not the 62 MB they move)
   if (eae_geo_mult > 1) blocks_per_desc = blocks_per_desc / eae_geo_mult > 16 ? blocks_per_desc / eae_geo_mult : 16;
   eae_launch(pack_all_kernel, pack_all_kernel_g, dim3(blocks_per_desc, ndesc), dim3(256), 0, st, pa);
+  EAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// Workgroups of a descriptor in the flattened launch: one pass of its loop per workgroup (2048 destination elements, one 64 x 64
+// tile, 256 (a, b) pairs of a 3 x 3 weight, 256 (row, channel) pairs of a projection), at most 1024.
+static int pack_desc_blocks(const PackDesc& d) {
+  long long items;
+  const bool big_rpt = d.mode == PACK_FC_ROWPERM_TRANS && !d.out_f32 && (long long)d.d2 * (d.d1 / 64) * (d.d0 / 64) >= 1024;
+  const bool big_kp = (d.mode == PACK_FC_ROWMAJOR_KPERM || d.mode == PACK_FC_TRANS_KPERM) && !d.out_f32 && (d.d2 & 63) == 0 && (d.d1 & 63) == 0 &&
+                      (d.d0 & 63) == 0 && (long long)d.d0 * (d.d1 / 64) * (d.d2 / 64) >= 1024;
+  if (d.q_layer >= 0) items = (d.count + 2047) / 2048;
+  else if ((d.mode == PACK_3x3_P1 || d.mode == PACK_3x3_P2) && !d.out_f32) items = ((long long)d.d0 * d.d1 + 255) / 256;
+  else if (big_rpt) items = (long long)d.d2 * (d.d1 / 64) * (d.d0 / 64);
+  else if (big_kp) items = (long long)d.d0 * (d.d1 / 64) * (d.d2 / 64);
+  else if ((d.mode == PACK_FC_ROWMAJOR_KPERM || d.mode == PACK_FC_TRANS_KPERM) && (d.d2 & 3) == 0 && !d.out_f32) items = ((long long)d.d0 * d.d1 + 255) / 256;
+  else items = (d.count + 2047) / 2048;
+  if (items < 1) items = 1;
+  if (items > 1024) items = 1024;
+  return (int)items;
+}
+int eae_pack_assign_blocks(PackDesc* descs, int ndesc, unsigned short* blkmap, int cap) {
+  int tot = 0;
+  for (int i = 0; i < ndesc; ++i) {
+    descs[i].blk0 = tot; descs[i].nblk = pack_desc_blocks(descs[i]);
+    for (int b = 0; b < descs[i].nblk; ++b) { if (tot + b >= cap) return -1; blkmap[tot + b] = (unsigned short)i; }
+    tot += descs[i].nblk;
+  }
+  return tot;
+}
+int eae_launch_pack_flat(hipStream_t st, const PackDesc* descs_all, const unsigned short* blkmap, int blk_begin, int blk_count, const float* params,
+                         void* pack_base, Fp8State* q, unsigned* clear_word) {
+  if (blk_count <= 0) return 0;
+  const PackAllArgs pa = {descs_all, params, (uint8_t*)pack_base, q, clear_word, blkmap, blk_begin};
+  eae_launch(pack_all_kernel, pack_all_kernel_g, dim3(blk_count), dim3(256), 0, st, pa);
   EAE_LAUNCH_CHECK();
   return 0;
 }
@@ -515,6 +556,18 @@ void eae_fp8_state_init(Fp8State* h) {
 // Fused multi-tensor Adam over the flat fp32 arenas (torch.optim.Adam defaults, R.md:624; L2 decay for the MLP, R.md:2625)
 //   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
 // ---------------------------------------------------------------------------------------------------------------
+// One element of the update with every rounding step written out (no fp contraction left to the compiler): the eager step's
+// adam_kernel and the graph path's adam_dyn_kernel must agree bit for bit (tests/test_gpu_ae.py::test_graph_replay_equals_eager),
+// and a refactoring of either kernel must not move a rounding -- round 4 found the compiler fusing  b2*v + ((1-b2)*g)*g  as
+// fma(g, t, b2*v) in one of them and as fma(b2, v, g*t) in the other after the first was turned into an inlined body.
+__device__ __forceinline__ EAE_NO_PK void adam_update(float& p, float gj, float& m, float& v, float b1, float b2, float step_size, float bc2_sqrt, float eps) {
+#pragma clang fp contract(off)
+  m = __builtin_fmaf(1.f - b1, gj - m, m);                   // exp_avg.lerp_(grad, 1-beta1)
+  const float t = (1.f - b2) * gj;
+  v = __builtin_fmaf(b2, v, gj * t);                         // mul_(beta2).addcmul_(grad, grad, 1-beta2)
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = __builtin_fmaf(-step_size, m / denom, p);
+}
 struct AdamArgs {
   float* p; const float* g; float* m; float* v; long n4; float b1, b2, step_size, bc2_sqrt, eps, wd, gscale; uint4* zbuf; long zn16;
   const unsigned* bad; const unsigned* bad2; float* nan_out; int nan_fill;
@@ -552,11 +605,8 @@ __device__ __forceinline__ EAE_NO_PK void adam_body(const AdamArgs& aa) {
     float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float gj = G[j] * gscale + wd * P[j];
-      M[j] = M[j] + (1.f - b1) * (gj - M[j]);            // exp_avg.lerp_(grad, 1-beta1)
-      V[j] = b2 * V[j] + (1.f - b2) * gj * gj;            // mul_(beta2).addcmul_(grad, grad, 1-beta2)
-      float denom = sqrtf(V[j]) / bc2_sqrt + eps;
-      P[j] -= step_size * (M[j] / denom);
+      const float wp = wd * P[j];
+      adam_update(P[j], __builtin_fmaf(G[j], gscale, wp), M[j], V[j], b1, b2, step_size, bc2_sqrt, eps);
     }
     reinterpret_cast<float4*>(p)[i] = pp;
     reinterpret_cast<float4*>(m)[i] = mm;
@@ -586,11 +636,7 @@ __global__ EAE_NO_PK __launch_bounds__(256) void adam_dyn_kernel(float* __restri
     float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float gj = G[j] + wd * P[j];
-      M[j] = M[j] + (1.f - b1) * (gj - M[j]);
-      V[j] = b2 * V[j] + (1.f - b2) * gj * gj;
-      float denom = sqrtf(V[j]) / bc2_sqrt + eps;
-      P[j] -= step_size * (M[j] / denom);
+      adam_update(P[j], __builtin_fmaf(wd, P[j], G[j]), M[j], V[j], b1, b2, step_size, bc2_sqrt, eps);
     }
     reinterpret_cast<float4*>(p)[i] = pp;
     reinterpret_cast<float4*>(m)[i] = mm;
