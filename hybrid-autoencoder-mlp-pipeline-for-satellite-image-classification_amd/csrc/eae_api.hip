@@ -180,6 +180,9 @@ struct eae_ctx {
   bool use_gates = true;           // device-side gates instead of event records on the caller's stream (EAE_FORK_EVENTS=1: events)
   unsigned long long gate_limit = 3000000000ULL;     // gate spin bound in 100 MHz ticks (30 s; EAE_GATE_TIMEOUT_MS, 0 = unbounded)
   float* last_loss = nullptr;      // the caller's loss_last buffer of the most recent step: poisoned with NaN when a gate has timed out
+  bool streams_exposed = false;     // eae_side_stream() handed a side stream to the caller: it is never replaced afterwards
+  hipStream_t probed_user = nullptr; bool probed = false;   // streams_distinct(): the caller's stream the side streams were checked against
+  int side_prio = 0;
   hipStream_t own_main = nullptr;  // capture is not permitted on the legacy default stream: graphs run here, bracketed by events
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   static constexpr int NEV = 16;
@@ -418,6 +421,7 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     const int side_prio = getenv("EAE_SIDE_PRIO_LOW") ? prio_lo : 0;
+    c->side_prio = side_prio;
     e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, side_prio);
     for (int i = 0; i < c->nx && e == hipSuccess; ++i) {
       e = hipStreamCreateWithPriority(&c->sidex[i], hipStreamNonBlocking, side_prio);
@@ -714,6 +718,59 @@ int join_side(eae_ctx* c, hipStream_t st) {
     EAE_HIP(hipStreamWaitEvent(st, c->ev_joinx[i], 0));
   }
   c->side_used = 0;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The caller's stream and the side streams must reach the GPU through DIFFERENT hardware queues: ROCm multiplexes a process's streams
+// onto 4 hardware queues, which one a stream gets depends on the streams alive when it was created, and two streams that share a
+// queue run one after the other (measured: the grouped B=64 step 0.73 instead of 0.62 ms in a process that had trained other
+// contexts from worker threads before; bench.py's grid leg).  Checked once per (context, caller's stream) before the first step:
+// a gate on stream A waits (bounded, 2 ms) for a word that a kernel enqueued AFTERWARDS on stream B publishes -- it times out exactly
+// when B's kernel cannot start beside it.  A side stream that collides is replaced by a fresh one (created while the colliding one
+// is still alive, so it lands elsewhere), up to 8 candidates.  EAE_STREAM_PROBE=0 switches the check off, =2 reports what it found.
+// ---------------------------------------------------------------------------------------------------------------------
+bool streams_share_queue(eae_ctx* c, hipStream_t a, hipStream_t b) {
+  unsigned* w = c->sigwords + 14;          // [14] probe word, [15] probe time-out (not the sticky word the optimizer looks at)
+  if (hipMemsetAsync(w, 0, 8, a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) return false;
+  GateArgs g = GateArgs();
+  g.word[0] = w; g.want[0] = 1; g.n = 1; g.timeout = w + 1; g.limit_ticks = 200000ULL;      // 2 ms of the 100 MHz clock
+  if (eae_launch_gate(a, g) || eae_launch_signal(b, w, 1)) return false;
+  hipStreamSynchronize(a); hipStreamSynchronize(b);
+  unsigned to = 0;
+  if (hipMemcpy(&to, w + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+  return to != 0;
+}
+int streams_distinct(eae_ctx* c, hipStream_t user) {
+  static const int mode = getenv("EAE_STREAM_PROBE") ? atoi(getenv("EAE_STREAM_PROBE")) : 1;
+  if (mode == 0 || !c->use_side || !c->use_gates || c->capturing || c->streams_exposed || eae_rec) return 0;
+  if (c->probed && c->probed_user == user) return 0;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(user, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;     // (not inside somebody's capture)
+  c->probed = true; c->probed_user = user;
+  EAE_HIP(hipDeviceSynchronize());
+  const int ns = 1 + c->nx;
+  int replaced = 0, left = 0;
+  std::vector<hipStream_t> drop;
+  for (int k = 0; k < ns; ++k) {
+    hipStream_t* slot = k == 0 ? &c->side : &c->sidex[k - 1];
+    for (int attempt = 0; attempt < 8; ++attempt) {
+      bool clash = streams_share_queue(c, *slot, user) || streams_share_queue(c, user, *slot);
+      for (int j = 0; j < k && !clash; ++j) {
+        hipStream_t other = j == 0 ? c->side : c->sidex[j - 1];
+        clash = streams_share_queue(c, *slot, other) || streams_share_queue(c, other, *slot);
+      }
+      if (!clash) break;
+      if (attempt == 7) { left++; break; }
+      hipStream_t fresh = nullptr;
+      EAE_HIP(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, c->side_prio));
+      drop.push_back(*slot);            // destroyed at the end: while it lives, the next candidate goes to another queue
+      *slot = fresh;
+      replaced++;
+    }
+  }
+  for (hipStream_t st : drop) hipStreamDestroy(st);
+  if (mode >= 2) fprintf(stderr, "[eae] stream probe: %d side stream(s) replaced, %d still share a hardware queue\n", replaced, left);
   return 0;
 }
 
@@ -1360,6 +1417,7 @@ extern "C" int eae_ae_backward(eae_ctx* c, void* stream, long long generation, c
 extern "C" int eae_ae_grad_step(eae_ctx* c, void* stream, const eae_step_io* io) {
   RC(check_io(c, io, true));
   hipStream_t st = (hipStream_t)stream;
+  RC(streams_distinct(c, st));
   RC(forward_impl(c, st, io, true));
   return backward_impl(c, st, io);
 }
@@ -1426,7 +1484,7 @@ extern "C" int eae_ae_grad_step_end(eae_ctx* c, void* stream) {
   c->fwd_ready = false; c->fwd_eval_ready = false; c->enc_ready = 0; c->dec_ready = 0;
   return rc;
 }
-extern "C" void* eae_side_stream(eae_ctx* c) { return c ? (void*)c->side : nullptr; }
+extern "C" void* eae_side_stream(eae_ctx* c) { if (c) c->streams_exposed = true; return c ? (void*)c->side : nullptr; }
 // Test / diagnostic access to the engine's workspace tensors of the most recent step (device synchronised first; bf16 NHWC, sized
 // for the context's max_batch): kind 0 = y[idx] (idx 0..3), 1 = gy[idx], 2 = u[idx] (0..2), 3 = gu[idx], 4 = dyy[idx] (1..3), 5 = dyu[idx].
 // Copies up to `bytes` to `host_dst`, returns the number of bytes copied or a negative status.
@@ -1466,6 +1524,7 @@ extern "C" int eae_adam_step_scaled(eae_ctx* c, void* stream, float lr, float we
 
 // The plain eager step: Adam takes its bias-correction scalars by value (one launch less on the critical path).
 static int train_step_eager(eae_ctx* c, hipStream_t st, const eae_step_io* io, float lr) {
+  RC(streams_distinct(c, st));
   int rc = forward_impl(c, st, io, true);
   c->adam_step += 1;               // (the bulk optimizer inside backward_impl needs this step's count; taken back when the step fails)
   if (!rc) rc = backward_impl(c, st, io, nullptr, 0, &lr);
@@ -1583,6 +1642,7 @@ int group_run(int what, eae_ctx* const* ctxs, int n, int mult, void* stream, con
       return eae_set_error(EAE_ERR_STATE, "group call: members must share the stream layout, with profiling, fp8 and data parallel off");
     for (int j = 0; j < k; ++j) if (ctxs[j] == c) return eae_set_error(EAE_ERR_ARG, "group call: a context appears twice");
   }
+  RC(streams_distinct(c0, user));
   static thread_local std::vector<GroupRec> recs;
   if ((int)recs.size() < n) recs.resize(n);
   static const bool timing = getenv("EAE_GROUP_TIMING") != nullptr;      // diagnostic: host microseconds of the phases, every 100th call
@@ -1904,6 +1964,7 @@ extern "C" int eae_ae_dp_train_step(eae_ctx* c, void* stream, const eae_step_io*
   if (!c->M || !c->V) return eae_set_error(EAE_ERR_STATE, "adam: moment arenas must be bound");
   hipStream_t st = (hipStream_t)stream;
   const bool ov = overlap != 0 && c->use_side;
+  RC(streams_distinct(c, st));
   if (ov && !eae_dp_stream(c, 0)) return eae_set_error(EAE_ERR_HIP, "dp_train_step: cannot create the hand-off stream");
   RC(forward_impl(c, st, io, true));
   RC(backward_impl(c, st, io));             // with a hand-off stream: dp_stream[0] is now ordered after gradient tensors 18..37

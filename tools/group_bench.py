@@ -18,6 +18,14 @@ steps = int(os.environ.get("GB_STEPS", "200"))
 ks = [int(v) for v in sys.argv[1:]] or [1, 2, 4, 8, 16]
 x = torch.rand((B, 3, 64, 64), device="cuda")
 y = torch.randint(0, 10, (B,), device="cuda")
+pre = int(os.environ.get("GB_PRE", "0"))          # contexts (and their streams) created before the group's: the streams' hardware queues depend on it
+keep_pre = []
+for i in range(pre):
+    m = eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=10).cuda().train()
+    keep_pre.append((m, engine_for(m, max_batch=B)))
+if os.environ.get("GB_PRE_DROP", "1") == "1":
+    keep_pre.clear()
+    torch.cuda.empty_cache()
 for k in ks:
     engs = []
     for i in range(k):
