@@ -224,6 +224,27 @@ def side_workload(args, device):
     tools/profile_round.sh can put rocprofv3 around it (kernel stats + PMC passes per workload) and the line carries its roofline."""
     import eae_amd
     from eae_amd.engine import engine_for
+    if args.workload == "grid8":
+        # the notebook's own batch size, eight grid configurations stepped as one group (configs.grid_b64's grouped leg, alone, for rocprofv3)
+        from eae_amd.engine import AEEngine
+        engs = []
+        for i in range(8):
+            torch.manual_seed(100 + i)
+            m = eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=10).to(device).train()
+            engs.append((m, engine_for(m, max_batch=64)))
+        es = [e for _, e in engs]
+        x, y = make_batch(64, device, seed=4321)
+        xs, ys, al, lr = [x] * 8, [y] * 8, [ALPHA + i for i in range(8)], [LR] * 8
+        sec = time_steps(lambda: AEEngine.group_train_step(es, xs, ys, al, lr), args.steps, args.warmup)
+        if any(e.gate_timeouts() for e in es):
+            raise SystemExit("a gate time-out in the timed region")
+        print(json.dumps({"metric": "EuroSAT 64x64 RGB images/sec (AE+MLP train step)", "value": round(8 * 64 / sec, 1), "unit": "images/s", "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * sec, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": "BASELINE configs[2]'s step at the notebook's batch size 64, 8 grid configurations per grouped step "
+                                                 "(eae_group_train_step)", "per_gpu_batch": 512, "global_batch": 512, "parallelism": "single",
+                                     "note": "NOT the headline configuration; one 'step' = one grouped step of 8 x 64 images"}}), flush=True)
+        return
     if args.workload == "c2":
         batch = 256 if args.batch == BATCH else args.batch
         torch.manual_seed(0)
@@ -264,7 +285,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configs[1] measurement")
-    ap.add_argument("--workload", choices=("c3", "c2", "c5fp8", "c5bf16"), default="c3",
+    ap.add_argument("--workload", choices=("c3", "c2", "c5fp8", "c5bf16", "grid8"), default="c3",
                     help="c3 = BASELINE configs[2], the headline (default); the others run the same loop over configs[1] / configs[4]'s shape")
     args = ap.parse_args()
 

@@ -662,8 +662,8 @@ int sq_commit(eae_ctx* c, hipStream_t st) {
   } else {
     hipEvent_t ev = c->ev_fork[c->ev_i];
     c->ev_i = (c->ev_i + 1) % eae_ctx::NEV;
-    EAE_HIP(hipEventRecord(ev, st));
-    for (int k = 0; k < ns; ++k) if (used & (1u << k)) EAE_HIP(hipStreamWaitEvent(side_stream(c, k), ev, 0));
+    EAE_HIP(eae_event_record(ev, st));
+    for (int k = 0; k < ns; ++k) if (used & (1u << k)) EAE_HIP(eae_stream_wait_event(side_stream(c, k), ev));
   }
   c->sq_wait = 0;
   c->side_used |= used;
@@ -677,8 +677,8 @@ int sq_commit(eae_ctx* c, hipStream_t st) {
 int fold_side2(eae_ctx* c) {
   if (!c->use_side) return 0;
   for (int i = 0; i < c->nx; ++i) {
-    EAE_HIP(hipEventRecord(c->ev_sx[i], c->sidex[i]));
-    EAE_HIP(hipStreamWaitEvent(c->side, c->ev_sx[i], 0));
+    EAE_HIP(eae_event_record(c->ev_sx[i], c->sidex[i]));
+    EAE_HIP(eae_stream_wait_event(c->side, c->ev_sx[i]));
   }
   return 0;
 }
@@ -711,11 +711,11 @@ int join_side(eae_ctx* c, hipStream_t st) {
     return 0;
   }
   RC(sq_commit(c, st));
-  EAE_HIP(hipEventRecord(c->ev_join, c->side));
-  EAE_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
+  EAE_HIP(eae_event_record(c->ev_join, c->side));
+  EAE_HIP(eae_stream_wait_event(st, c->ev_join));
   for (int i = 0; i < c->nx; ++i) {
-    EAE_HIP(hipEventRecord(c->ev_joinx[i], c->sidex[i]));
-    EAE_HIP(hipStreamWaitEvent(st, c->ev_joinx[i], 0));
+    EAE_HIP(eae_event_record(c->ev_joinx[i], c->sidex[i]));
+    EAE_HIP(eae_stream_wait_event(st, c->ev_joinx[i]));
   }
   c->side_used = 0;
   return 0;
@@ -1638,7 +1638,7 @@ int group_run(int what, eae_ctx* const* ctxs, int n, int mult, void* stream, con
     eae_ctx* c = ctxs[k];
     RC(check_io(c, &ios[k], what == 0));
     if (what == 0 && (!c->M || !c->V)) return eae_set_error(EAE_ERR_STATE, "adam: moment arenas must be bound");
-    if (c->prof_on || c->fp8 || c->dp_comm || !c->use_gates || c->use_side != c0->use_side || c->nx != c0->nx)
+    if (c->prof_on || c->fp8 || c->dp_comm || c->use_gates != c0->use_gates || c->use_side != c0->use_side || c->nx != c0->nx)
       return eae_set_error(EAE_ERR_STATE, "group call: members must share the stream layout, with profiling, fp8 and data parallel off");
     for (int j = 0; j < k; ++j) if (ctxs[j] == c) return eae_set_error(EAE_ERR_ARG, "group call: a context appears twice");
   }

@@ -22,7 +22,16 @@ HBM, MFMA = 8000.0, 2500.0          # GB/s, TFLOP/s (dense bf16)
 WL = {"b512": ("BASELINE configs[2] (headline): joint step, B=512, 64x64, L=64", 512, 64, 64),
       "c2": ("BASELINE configs[1]: reconstruction only, B=256, 64x64, L=64", 256, 64, 64),
       "c5fp8": ("BASELINE configs[4]'s per-GPU shape, fp8 GEMM operands: joint step, B=128, 256x256, L=256", 128, 256, 256),
-      "c5bf16": ("the same shape through the bf16 kernels: joint step, B=128, 256x256, L=256", 128, 256, 256)}
+      "c5bf16": ("the same shape through the bf16 kernels: joint step, B=128, 256x256, L=256", 128, 256, 256),
+      "grid8": ("the notebook's batch size: 8 grid configurations x B=64 per GROUPED step (eae_group_train_step), 64x64, L=64 -- "
+                "per launch = all 8 members; Adam / pack rows move 8 models' parameters", 512, 64, 64)}
+GROUP = {"grid8": 8}
+
+
+def ungroup(n):
+    """kernel name of a grouped twin -> the single kernel's (site / role lookup)"""
+    n = re.sub(r"_g(<|\()", r"\1", n)
+    return re.sub(r"\(GroupPack<(\w+)>, int\)", r"(\1)", n)
 HELPERS = ("bn_finalize", "bn_bwd_finalize", "reduce_slices", "fc_splitk_reduce", "head_kernel", "loss_finalize", "signal_kernel",
            "fp8_", "amax", "quant", "scale")
 
@@ -73,7 +82,9 @@ def table(rnd, tag):
     print("| kernel | role | calls | µs in the step | µs alone | % of kernel time | alg MB | GB/s | HBM frac | HBM frac alone | TFLOP/s | MFMA frac | PMC MB | PMC/alg | MFMA busy |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     lines = []
-    for n, r in work.items():
+    ng = GROUP.get(tag, 1)
+    for n0, r in work.items():
+        n = ungroup(n0)
         us = float(r["AverageNs"]) / 1e3
         pct = 100.0 * float(r["TotalDurationNs"]) / tot
         site = PH.site_of(n)
@@ -85,12 +96,12 @@ def table(rnd, tag):
             if fm:
                 role, byts, fl = fm
             elif n.startswith(("adam_kernel", "void adam_kernel", "adam_dyn_kernel", "void adam_dyn_kernel")):
-                role, byts, fl = "Adam over the flat arenas (p, g, m, v read; p, m, v write)", 7 * 4 * n_params(hw, L), 0.0
+                role, byts, fl = "Adam over the flat arenas (p, g, m, v read; p, m, v write)", ng * 7 * 4 * n_params(hw, L), 0.0
             elif "pack_all_kernel" in n:
-                role, byts, fl = "fp32 master weights -> bf16 kernel layouts", (4 + 2 * 2) * n_params(hw, L), 0.0
+                role, byts, fl = "fp32 master weights -> bf16 kernel layouts", ng * (4 + 2 * 2) * n_params(hw, L), 0.0
             else:
                 continue
-        k = pmc.get(n, {})
+        k = pmc.get(n0, {})
         tr, mu = k.get("traffic_bytes"), k.get("mfma_util")
         short = n.split("(")[0].replace("void ", "")
         al = alone.get(site) if site is not None else None
@@ -107,7 +118,7 @@ def table(rnd, tag):
     for _, l in sorted(lines, key=lambda t: -t[0]):
         print(l)
     small = [(n.split("(")[0].replace("void ", ""), float(r["AverageNs"]) / 1e3, int(r["Calls"]), 100.0 * float(r["TotalDurationNs"]) / tot)
-             for n, r in work.items() if PH.site_of(n) is None and any(k in n for k in HELPERS)]
+             for n, r in work.items() if PH.site_of(ungroup(n)) is None and any(k in n for k in HELPERS)]
     if small:
         print("\nHelpers (latency-bound, no meaningful roofline; average per launch, share of kernel time): " +
               "; ".join(f"`{n}` {us:.1f} µs × {c} ({p:.1f} %)" for n, us, c, p in sorted(small, key=lambda t: -t[3])))
@@ -140,7 +151,7 @@ def main():
           "per-op C ABI, back to back on an otherwise idle GPU (`tools/kbench_sites.py`; weight-gradient rows include their slice-reduction "
           "launch, so they can exceed the in-step kernel alone; the fp8 table shows its bf16 twins): the gap to `µs in the step` is "
           "contention -- side streams beside the backward-data chain -- not kernel quality.")
-    for tag in ("b512", "c2", "c5fp8", "c5bf16"):
+    for tag in ("b512", "c2", "c5fp8", "c5bf16", "grid8"):
         table(rnd, tag)
 
 

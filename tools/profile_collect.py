@@ -19,7 +19,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BATCH = {"c3": 512, "c2": 256, "c5fp8": 128, "c5bf16": 128}
+BATCH = {"c3": 512, "c2": 256, "c5fp8": 128, "c5bf16": 128, "grid8": 512}
 TAG = {"c3": "b512"}
 
 
@@ -39,7 +39,7 @@ def one(path_glob):
 
 def main():
     rnd, commit = sys.argv[1], sys.argv[2]
-    wls = sys.argv[3:] or ["c3", "c2", "c5fp8", "c5bf16"]
+    wls = sys.argv[3:] or ["c3", "c2", "c5fp8", "c5bf16", "grid8"]
     meta = {"commit": commit, "collected": time.strftime("%Y-%m-%d"), "tool": "tools/profile_round.sh + tools/profile_collect.py", "workloads": {}}
     for wl in wls:
         d = os.path.join(ROOT, "gpurun_out", f"prof_{rnd}", wl)
