@@ -48,6 +48,8 @@ def site_of(name):
     if not m:
         return None
     fam, args = m.group(1), [int(a) for a in m.group(2).split(",")]
+    if fam.endswith("_kernel_g"):          # the grouped twin of a kernel (csrc/eae_group.h): same template arguments, same launch site
+        fam = fam[:-2]
     try:
         if fam in ("igemm_s2_kernel", "igemm2_s2_kernel", "igemm8_s2_kernel"):
             kind, cin, cout, src, epi = args[0], args[1], args[2], args[7], args[8]

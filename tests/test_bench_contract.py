@@ -50,7 +50,9 @@ def test_site_of_and_site_model_on_every_kernel_name_of_the_committed_summaries(
              "void wgrad_s2_kernel<256, 128, 4, 4, 8, 2, 1>(WgradArgs)": S(3, 2),
              "void deconv4_loss_kernel<1>(Deconv4Args)": S(7, 0), "void edge_wgrad_kernel<0, 2>(EdgeWgradArgs)": S(0, 2),
              "void edge_wgrad_kernel<1, 1>(EdgeWgradArgs)": S(7, 2), "void edge_conv_kernel<1, 1>(EdgeArgs)": S(7, 1),
-             "void edge_conv_kernel<0, 0>(EdgeArgs)": S(0, 0), "void igemm8_s2_kernel<1, 64, 32, 32, 16, 8, 1, 2, 1>(ConvArgs)": S(1, 1)}
+             "void edge_conv_kernel<0, 0>(EdgeArgs)": S(0, 0), "void igemm8_s2_kernel<1, 64, 32, 32, 16, 8, 1, 2, 1>(ConvArgs)": S(1, 1),
+             "void wgrad_s2_kernel_g<64, 32, 16, 8, 1, 1, 2>(GroupPack<WgradArgs>, int)": S(6, 2),          # grouped twins (eae_group.h)
+             "void igemm_s2_kernel_g<0, 32, 64, 64, 16, 8, 1, 1, 0>(GroupPack<ConvArgs>, int)": S(1, 0)}
     for n, s in known.items():
         assert ph.site_of(n) == s, n
     for n in ("adam_kernel(AdamArgs)", "void head_kernel<16>(HeadArgs)", "gate_kernel(GateArgs)", "void fc_nt_kernel<1, 0>(FcNtArgs)"):
