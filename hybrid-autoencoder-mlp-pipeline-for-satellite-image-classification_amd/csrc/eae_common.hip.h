@@ -327,4 +327,9 @@ __device__ __forceinline__ void eae_signal(unsigned* sig, unsigned val) {
     __hip_atomic_store(sig, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// the same store by the workgroup the caller elects (kernels whose workgroup ids are remapped: the grouped twins' XCD-aware map)
+__device__ __forceinline__ void eae_signal_first(unsigned* sig, unsigned val, bool first) {
+  if (sig != nullptr && first && threadIdx.x == 0) __hip_atomic_store(sig, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #define EAE_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return eae_set_error(-3, hipGetErrorString(e__)); } while (0)

@@ -328,7 +328,7 @@ __device__ __forceinline__ uint32_t amax_pk(uint32_t run, const uint4& o) {
 // Q = 0: bf16 operands;  Q = 1: fp8 operands (weights e4m3 from an fp8 pack, pixel fragments converted in registers from the bf16
 // patch: e4m3 for activations, e5m2 for SRC_BNBWD gradients), fp32 accumulation either way
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI, int Q>
-__device__ __forceinline__ void igemm_body(const ConvArgs& a) {
+__device__ __forceinline__ void igemm_body(const ConvArgs& a, const int li_given = -1) {     // li_given >= 0: the workgroup's logical id (grouped twin, group_xcd_map)
   using G = Geo<KIND, TW, TH, NI>;
   static_assert(G::P == 64 || G::P == 128, "tile must hold 64 or 128 positions");
   static_assert(CIN % 32 == 0 && COUT % BN == 0 && (BN == 32 || BN == 64), "shape");
@@ -362,7 +362,8 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   int tile_id, nblk;
   {
     const int bid = blockIdx.x;
-    if (NB == 1) { tile_id = bid; nblk = 0; }
+    if (li_given >= 0) { nblk = NB == 1 ? 0 : li_given % NB; tile_id = NB == 1 ? li_given : li_given / NB; }
+    else if (NB == 1) { tile_id = bid; nblk = 0; }
     else if ((a.ntiles * NB) % 8 == 0) { const int li = (bid & 7) * ((a.ntiles * NB) >> 3) + (bid >> 3); nblk = li % NB; tile_id = li / NB; }   // contiguous run of (tile, block) pairs per XCD
     else { nblk = bid % NB; tile_id = bid / NB; }
   }
@@ -373,7 +374,8 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   const int n0 = nblk * BN;
   const int iy0 = (KIND == KIND_CONV) ? 2 * tyb * TH - 1 : tyb * TH, ix0 = (KIND == KIND_CONV) ? 2 * txb * TW - 1 : txb * TW;
 
-  eae_signal(a.sig, a.sig_val);
+  const bool first_wg = li_given >= 0 ? li_given == 0 : blockIdx.x == 0;      // elected workgroup: publishes the progress value, writes the folded tables
+  eae_signal_first(a.sig, a.sig_val, first_wg);
   EAE_STAMP(0);
   EAE_STAMP_WG(0);
   f32x4 acc[NPH][MT];
@@ -468,17 +470,17 @@ __device__ __forceinline__ void igemm_body(const ConvArgs& a) {
   if (folded) bn_fold_load<CIN>(a.fold, fr);
   if (folded_b) bn_fold_bwd_load<CIN>(a.bfold, frb);
   if (EARLY_TABLE && folded_b) {
-    bn_fold_bwd_finish<CIN>(a.bfold, frb, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0);
+    bn_fold_bwd_finish<CIN>(a.bfold, frb, coef_tab, reinterpret_cast<long long*>(smem), first_wg);
     coefp = coef_tab;
   }
   if (SRC != SRC_BNBWD) load_w(0);
   issue(0, false);
   if (folded) {
-    bn_fold_fwd_finish<CIN>(a.fold, fr, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0);
+    bn_fold_fwd_finish<CIN>(a.fold, fr, coef_tab, reinterpret_cast<long long*>(smem), first_wg);
     coefp = coef_tab;
   }
   if (!EARLY_TABLE && folded_b) {
-    bn_fold_bwd_finish<CIN>(a.bfold, frb, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0);
+    bn_fold_bwd_finish<CIN>(a.bfold, frb, coef_tab, reinterpret_cast<long long*>(smem), first_wg);
     coefp = coef_tab;
   }
   // two source tensors' raw pieces are in registers while the table is built: the weight fragments (L2-resident, needed only at
@@ -697,7 +699,9 @@ __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void ig
 // grouped twin (eae_group.h): workgroup z runs the body with member z's arguments
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
 __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void igemm_s2_kernel_g(GroupPack<ConvArgs> p, int gz) {
-  igemm_body<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI, 0>(group_args<ConvArgs>(gz));
+  unsigned member; int li;
+  group_xcd_map(member, li);           // a member's tiles on one XCD: its weights and the channel blocks' shared patches stay in that L2
+  igemm_body<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI, 0>(group_args_of<ConvArgs>(member), li);
 }
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI>
 __global__ __launch_bounds__(256, ig_occ(KIND, CIN, COUT, NI * TH * TW)) void igemm8_s2_kernel(ConvArgs a) {

@@ -27,7 +27,7 @@ constexpr size_t igemm2_smem() {
 }
 
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI, int NBL>
-__device__ __forceinline__ void igemm2_body(const ConvArgs& a) {
+__device__ __forceinline__ void igemm2_body(const ConvArgs& a, const int li_given = -1) {
   using G = Geo<KIND, TW, TH, NI>;
   static_assert(G::P == 64 || G::P == 128, "tile must hold 64 or 128 positions");
   static_assert(CIN % 32 == 0 && CIN >= 64 && COUT % BN == 0 && (BN == 32 || BN == 64), "shape");
@@ -46,7 +46,8 @@ __device__ __forceinline__ void igemm2_body(const ConvArgs& a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0-3 consumers, 4-7 producers
-  eae_signal(a.sig, a.sig_val);
+  const bool first_wg = li_given >= 0 ? li_given == 0 : blockIdx.x == 0;
+  eae_signal_first(a.sig, a.sig_val, first_wg);
   const int Hout = (KIND == KIND_CONV) ? a.Hin >> 1 : a.Hin * 2, Wout = (KIND == KIND_CONV) ? a.Win >> 1 : a.Win * 2;
   const int Hpos = (KIND == KIND_CONV) ? Hout : a.Hin, Wpos = (KIND == KIND_CONV) ? Wout : a.Win;   // position grid
   const int tiles_x = Wpos / TW, tiles_y = Hpos / TH;
@@ -54,7 +55,8 @@ __device__ __forceinline__ void igemm2_body(const ConvArgs& a) {
   int tile_id, nblk;
   {
     const int bid = blockIdx.x;
-    if (NB == 1 || NBL > 1) { tile_id = bid; nblk = 0; }
+    if (li_given >= 0) { const bool one = NB == 1 || NBL > 1; nblk = one ? 0 : li_given % NB; tile_id = one ? li_given : li_given / NB; }
+    else if (NB == 1 || NBL > 1) { tile_id = bid; nblk = 0; }
     else if ((a.ntiles * NB) % 8 == 0) { const int li = (bid & 7) * ((a.ntiles * NB) >> 3) + (bid >> 3); nblk = li % NB; tile_id = li / NB; }   // contiguous run of (tile, block) pairs per XCD
     else { nblk = bid % NB; tile_id = bid / NB; }
   }
@@ -116,11 +118,11 @@ __device__ __forceinline__ void igemm2_body(const ConvArgs& a) {
     issue(1, rb);
     EAE_STAMP_T(101, 256);
     if (folded) {
-      bn_fold_fwd_finish<CIN>(a.fold, fr, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0, ptid);   // two barriers
+      bn_fold_fwd_finish<CIN>(a.fold, fr, coef_tab, reinterpret_cast<long long*>(smem), first_wg, ptid);   // two barriers
       coefp = coef_tab;
     }
     if (folded_b) {
-      bn_fold_bwd_finish<CIN>(a.bfold, frb, coef_tab, reinterpret_cast<long long*>(smem), blockIdx.x == 0, ptid);  // two barriers
+      bn_fold_bwd_finish<CIN>(a.bfold, frb, coef_tab, reinterpret_cast<long long*>(smem), first_wg, ptid);  // two barriers
       coefp = coef_tab;
     }
     EAE_STAMP_T(102, 256);
@@ -312,5 +314,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 template <int KIND, int CIN, int COUT, int BN, int TW, int TH, int NI, int SRC, int EPI, int NBL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm2_s2_kernel_g(GroupPack<ConvArgs> p, int gz) {
-  igemm2_body<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI, NBL>(group_args<ConvArgs>(gz));
+  unsigned member; int li;
+  group_xcd_map(member, li);
+  igemm2_body<KIND, CIN, COUT, BN, TW, TH, NI, SRC, EPI, NBL>(group_args_of<ConvArgs>(member), li);
 }

@@ -71,7 +71,7 @@ struct WgRaw {
 // Q = 1: both fragment operands converted in registers to fp8 right before the MFMA (e5m2 for the gradient operand -- SRC_BNBWD or
 // SRC_RAWG --, e4m3 for the activation operand), accumulators rescaled in the epilogue (see igemm_body, eae_igemm.hip.h)
 template <int CS, int CB, int TW, int TH, int NI, int SMODE, int BMODE, int Q>
-__device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int li_given = -1) {     // li_given >= 0: the workgroup's logical id (grouped twin)
   static_assert(NI * TH * TW == 128, "tile must hold 128 positions");
   static_assert(NI <= 8, "image index of a piece is kept in 4 bits");
   constexpr bool SG = (SMODE == SRC_BNBWD || SMODE == SRC_RAWG), BG = (BMODE == SRC_BNBWD || BMODE == SRC_RAWG);
@@ -91,7 +91,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   {
     const int bid = blockIdx.x;
     const int total = a.nslices * NBLK;
-    if (NBLK == 1) { slice = bid; oblk = 0; }
+    if (li_given >= 0) { slice = li_given / NBLK; oblk = li_given % NBLK; }
+    else if (NBLK == 1) { slice = bid; oblk = 0; }
     else if (total % 8 == 0) {
       // every XCD takes a CONTIGUOUS run of (slice, block) pairs: the blocks of a slice land on as few XCDs as possible (one when
       // nslices % 8 == 0; two at 4 slices x 16 blocks, where the round-1 fallback `bid % NBLK` spread a slice's blocks over all eight
@@ -319,7 +320,9 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_s2_kernel(WgradArgs a) {
 }
 template <int CS, int CB, int TW, int TH, int NI, int SMODE, int BMODE>
 __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_s2_kernel_g(GroupPack<WgradArgs> p, int gz) {      // grouped twin (eae_group.h)
-  wgrad_body<CS, CB, TW, TH, NI, SMODE, BMODE, 0>(group_args<WgradArgs>(gz));
+  unsigned member; int li;
+  group_xcd_map(member, li);
+  wgrad_body<CS, CB, TW, TH, NI, SMODE, BMODE, 0>(group_args_of<WgradArgs>(member), li);
 }
 template <int CS, int CB, int TW, int TH, int NI, int SMODE, int BMODE>
 __global__ __launch_bounds__(WG_THREADS, 3) void wgrad8_s2_kernel(WgradArgs a) {
