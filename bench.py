@@ -13,6 +13,7 @@ Rank 0 prints ONE JSON line.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -157,10 +158,11 @@ def config5_leg(batch=128, steps=20, warmup=5, roofline=True):
 
 
 def grid_b64_leg(k=int(os.environ.get("EAE_GRID_K", "8")), steps=150, warmup=15):
-    """The reference's REAL workload (R.md:246, 599-711): batch 64, a grid of independent configurations.  `grouped`: K engine contexts
-    stepped by ONE sequence of grouped launches per step (include/eae.h eae_group_train_step -- what grid_search_autoencoder(grouped=K)
-    uses); `concurrent`: the round-3 way, 4 contexts on one stream + host thread each (train.run_concurrent); `k1`: one configuration.
-    `images_per_s` is the aggregate over the K configurations of the grouped leg."""
+    """The reference's REAL workload (R.md:246, 599-711): batch 64, a grid of independent configurations.  `grouped_one`: K engine
+    contexts stepped by ONE sequence of grouped launches per step (include/eae.h eae_group_train_step); `grouped`: two such groups at a
+    time from two host threads, one side stream per context -- what grid_search_autoencoder(grouped=K, concurrent_groups=2) does;
+    `concurrent`: the round-3 way, 4 contexts on one stream + host thread each (train.run_concurrent); `k1`: one configuration.
+    `images_per_s` is the aggregate over the 2 x K configurations of the `grouped` leg."""
     import eae_amd
     from eae_amd.engine import AEEngine, engine_for
     from eae_amd import train as T
@@ -186,32 +188,62 @@ def grid_b64_leg(k=int(os.environ.get("EAE_GRID_K", "8")), steps=150, warmup=15)
                 for _ in range(n):
                     e.train_step(x, y, ALPHA, 1e-3)
             return job
-        T.run_concurrent([job_of(e, warmup) for _, e in engs], kk)
+        T.run_concurrent([job_of(e, warmup) for _, e in engs], kk, static=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        T.run_concurrent([job_of(e, steps) for _, e in engs], kk)
+        T.run_concurrent([job_of(e, steps) for _, e in engs], kk, static=True)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         bad = [e.gate_timeouts() for _, e in engs]
         res[name] = {"configs": kk, "steps_each": steps, "images_per_s": round(kk * steps * 64 / el, 1),
                      "ms_per_step_per_config": round(1e3 * el / steps, 4), "gate_timeouts": sum(1 for b in bad if b)}
         del engs
+        gc.collect()
         torch.cuda.empty_cache()
-    engs = build(k, False)
-    es = [e for _, e in engs]
-    xs, ys, al, lr = [x] * k, [y] * k, [ALPHA + i for i in range(k)], [1e-3] * k
-    for _ in range(warmup):
-        AEEngine.group_train_step(es, xs, ys, al, lr)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        AEEngine.group_train_step(es, xs, ys, al, lr)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    res["grouped"] = {"configs": k, "steps_each": steps, "images_per_s": round(k * steps * 64 / el, 1), "ms_per_group_step": round(1e3 * el / steps, 4),
-                      "gate_timeouts": sum(1 for e in es if e.gate_timeouts())}
-    del engs, es
-    torch.cuda.empty_cache()
+    def grouped_leg(ngroups, side_streams):
+        groups = []
+        for g in range(ngroups):
+            es = []
+            for i in range(k):
+                torch.manual_seed(100 + g * k + i)
+                m = eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=10).cuda().train()
+                if side_streams:
+                    m._eae_side_streams = side_streams
+                es.append((m, engine_for(m, max_batch=64)))
+            groups.append(es)
+
+        def gjob(es, n):
+            engs = [e for _, e in es]
+            a = ([x] * k, [y] * k, [ALPHA + i for i in range(k)], [1e-3] * k)
+
+            def job():
+                for _ in range(n):
+                    AEEngine.group_train_step(engs, *a)
+            return job
+        if ngroups == 1:
+            gjob(groups[0], warmup)()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gjob(groups[0], steps)()
+        else:
+            T.run_concurrent([gjob(es, warmup) for es in groups], ngroups, static=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            T.run_concurrent([gjob(es, steps) for es in groups], ngroups, static=True)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out = {"groups": ngroups, "configs": ngroups * k, "steps_each": steps, "images_per_s": round(ngroups * k * steps * 64 / el, 1),
+               "ms_per_round_of_group_steps": round(1e3 * el / steps, 4), "side_streams_per_context": side_streams or 2,
+               "gate_timeouts": sum(1 for es in groups for _, e in es if e.gate_timeouts())}
+        del groups
+        gc.collect()                # (engine contexts sit in reference cycles: destroy them, and their claims on hardware queues, now)
+        torch.cuda.empty_cache()
+        return out
+    # one group of K (default stream layout), and what grid_search_autoencoder(grouped=K, concurrent_groups=2) does: two groups at a time
+    # from two host threads, one side stream per context (2 x 2 streams = the four hardware queues; one group's forward beside the
+    # other's backward)
+    res["grouped_one"] = grouped_leg(1, 0)
+    res["grouped"] = grouped_leg(2, 1)
     res["images_per_s"] = res["grouped"]["images_per_s"]
     return res
 

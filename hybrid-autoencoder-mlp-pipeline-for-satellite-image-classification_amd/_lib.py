@@ -71,6 +71,8 @@ _PROTOS = {
     "eae_group_train_step": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, vp, C.POINTER(EaeStepIO), C.POINTER(C.c_float)]),
     "eae_group_forward": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, vp, C.POINTER(EaeStepIO)]),
     "eae_set_geometry_mult": (C.c_int, [C.c_int]),
+    "eae_streams_share_queue": (C.c_int, [vp, vp]),
+    "eae_reserve_stream": (C.c_int, [vp, C.c_int]),
     "eae_sync_bn_acc_elems": (C.c_longlong, [vp]),
     "eae_set_sync_bn": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     "eae_encoder_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),

@@ -15,6 +15,8 @@
 #include <future>
 #include <memory>
 #include <thread>
+#include <mutex>
+#include <atomic>
 
 static thread_local std::string g_err;
 int eae_set_error(int code, const char* msg) { g_err = msg ? msg : "unknown error"; return code; }
@@ -180,6 +182,7 @@ struct eae_ctx {
   bool use_gates = true;           // device-side gates instead of event records on the caller's stream (EAE_FORK_EVENTS=1: events)
   unsigned long long gate_limit = 3000000000ULL;     // gate spin bound in 100 MHz ticks (30 s; EAE_GATE_TIMEOUT_MS, 0 = unbounded)
   float* last_loss = nullptr;      // the caller's loss_last buffer of the most recent step: poisoned with NaN when a gate has timed out
+  std::atomic<long long> last_step_ns{0};   // steady-clock time of the last step that went through streams_distinct (idle contexts' claims are ignored)
   bool streams_exposed = false;     // eae_side_stream() handed a side stream to the caller: it is never replaced afterwards
   hipStream_t probed_user = nullptr; bool probed = false;   // streams_distinct(): the caller's stream the side streams were checked against
   int side_prio = 0;
@@ -234,6 +237,32 @@ extern "C" int eae_ae_layout(const eae_config* cfg, long long* param_off, long l
   }
   if (bn_off) bn_off[14] = o;
   return 0;
+}
+
+// A stream of the engine's own.  EAE_DEDICATED_QUEUES=1: created with a full CU mask -- ROCm gives such a stream a hardware queue of
+// its own instead of one of the 4 queues the process's other streams are multiplexed onto (experiment).
+static hipError_t eae_new_stream(hipStream_t* st, int prio) {
+  static const bool dedicated = getenv("EAE_DEDICATED_QUEUES") && atoi(getenv("EAE_DEDICATED_QUEUES")) != 0;
+  if (dedicated) {
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) {
+      const int ncu = pr.multiProcessorCount;
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      for (int i = 0; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
+      if (hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()) == hipSuccess) return hipSuccess;
+    }
+  }
+  return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
+}
+extern "C" void* eae_stream_create_dedicated(void) {
+  hipStream_t st = nullptr;
+  int dev = 0; hipDeviceProp_t pr;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return nullptr;
+  const int ncu = pr.multiProcessorCount;
+  std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+  for (int i = 0; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) return nullptr;
+  return (void*)st;
 }
 
 extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
@@ -422,9 +451,9 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     const int side_prio = getenv("EAE_SIDE_PRIO_LOW") ? prio_lo : 0;
     c->side_prio = side_prio;
-    e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, side_prio);
+    e = eae_new_stream(&c->side, side_prio);
     for (int i = 0; i < c->nx && e == hipSuccess; ++i) {
-      e = hipStreamCreateWithPriority(&c->sidex[i], hipStreamNonBlocking, side_prio);
+      e = eae_new_stream(&c->sidex[i], side_prio);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_joinx[i], EV_FLAGS);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sx[i], EV_FLAGS);
     }
@@ -480,9 +509,11 @@ extern "C" int eae_profile_read2(eae_ctx* c, double* total_ms, double* empty_ms,
 extern "C" int eae_profile_read(eae_ctx* c, double* total_ms, long long* count) { return eae_profile_read2(c, total_ms, nullptr, count); }
 
 extern "C" int eae_dp_destroy(eae_ctx* c);
+namespace { void streams_forget(const eae_ctx* c); }
 extern "C" int eae_destroy(eae_ctx* c) {
   if (!c) return 0;
   hipDeviceSynchronize();
+  streams_forget(c);
   eae_dp_destroy(c);
   if (c->prof_ev[0]) for (int i = 0; i < 3 * eae_ctx::PROF_RING; ++i) hipEventDestroy(c->prof_ev[i]);
   for (int i = 0; i < c->ngraphs; ++i) {
@@ -726,52 +757,84 @@ int join_side(eae_ctx* c, hipStream_t st) {
 // onto 4 hardware queues, which one a stream gets depends on the streams alive when it was created, and two streams that share a
 // queue run one after the other (measured: the grouped B=64 step 0.73 instead of 0.62 ms in a process that had trained other
 // contexts from worker threads before; bench.py's grid leg).  Checked once per (context, caller's stream) before the first step:
-// a gate on stream A waits (bounded, 2 ms) for a word that a kernel enqueued AFTERWARDS on stream B publishes -- it times out exactly
+// a gate on stream A waits (bounded, 0.3 ms) for a word that a kernel enqueued AFTERWARDS on stream B publishes -- it times out exactly
 // when B's kernel cannot start beside it.  A side stream that collides is replaced by a fresh one (created while the colliding one
 // is still alive, so it lands elsewhere), up to 8 candidates.  EAE_STREAM_PROBE=0 switches the check off, =2 reports what it found.
 // ---------------------------------------------------------------------------------------------------------------------
-bool streams_share_queue(eae_ctx* c, hipStream_t a, hipStream_t b) {
-  unsigned* w = c->sigwords + 14;          // [14] probe word, [15] probe time-out (not the sticky word the optimizer looks at)
+// (two device words: [0] the word the gate waits for, [1] its time-out flag -- not the sticky word the optimizer looks at)
+bool streams_share_queue(unsigned* w, hipStream_t a, hipStream_t b) {
+  if (a == b) return true;
   if (hipMemsetAsync(w, 0, 8, a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) return false;
   GateArgs g = GateArgs();
-  g.word[0] = w; g.want[0] = 1; g.n = 1; g.timeout = w + 1; g.limit_ticks = 200000ULL;      // 2 ms of the 100 MHz clock
+  g.word[0] = w; g.want[0] = 1; g.n = 1; g.timeout = w + 1; g.limit_ticks = 30000ULL;      // 0.3 ms of the 100 MHz clock (a kernel that CAN start beside the gate does so within microseconds)
   if (eae_launch_gate(a, g) || eae_launch_signal(b, w, 1)) return false;
   hipStreamSynchronize(a); hipStreamSynchronize(b);
   unsigned to = 0;
   if (hipMemcpy(&to, w + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
   return to != 0;
 }
+bool streams_clash(unsigned* w, hipStream_t a, hipStream_t b) { return streams_share_queue(w, a, b) || streams_share_queue(w, b, a); }
+// Streams that steps are running on, process-wide: the caller's streams of probed contexts, their side streams, and streams a
+// driver has reserved for its worker threads (eae_reserve_stream: train.run_concurrent).  A context's side streams also keep clear of
+// these -- two groups stepped from two threads use four streams, and the GPU has four hardware queues.  One probe at a time.
+struct StreamRegistry {
+  std::mutex mu;
+  std::vector<std::pair<hipStream_t, const void*>> used;       // (stream, owner: a context, or nullptr for a reserved stream)
+};
+StreamRegistry& stream_registry() { static StreamRegistry r; return r; }
 int streams_distinct(eae_ctx* c, hipStream_t user) {
   static const int mode = getenv("EAE_STREAM_PROBE") ? atoi(getenv("EAE_STREAM_PROBE")) : 1;
   if (mode == 0 || !c->use_side || !c->use_gates || c->capturing || c->streams_exposed || eae_rec) return 0;
+  const long long now_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  c->last_step_ns.store(now_ns, std::memory_order_relaxed);
   if (c->probed && c->probed_user == user) return 0;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(user, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;     // (not inside somebody's capture)
+  StreamRegistry& reg = stream_registry();
+  std::lock_guard<std::mutex> lock(reg.mu);
   c->probed = true; c->probed_user = user;
   EAE_HIP(hipDeviceSynchronize());
+  unsigned* w = c->sigwords + 14;
+  // forget this context's earlier claims (a new caller's stream), collect the others'
+  for (size_t i = reg.used.size(); i-- > 0;) if (reg.used[i].second == c) reg.used.erase(reg.used.begin() + i);
+  std::vector<hipStream_t> others;
+  for (const auto& u : reg.used) {
+    if (u.first == user) continue;
+    const eae_ctx* o = static_cast<const eae_ctx*>(u.second);        // (a context that has not stepped for half a second is not in anybody's way)
+    if (o && now_ns - o->last_step_ns.load(std::memory_order_relaxed) > 500000000LL) continue;
+    others.push_back(u.first);
+  }
   const int ns = 1 + c->nx;
   int replaced = 0, left = 0;
   std::vector<hipStream_t> drop;
   for (int k = 0; k < ns; ++k) {
     hipStream_t* slot = k == 0 ? &c->side : &c->sidex[k - 1];
     for (int attempt = 0; attempt < 8; ++attempt) {
-      bool clash = streams_share_queue(c, *slot, user) || streams_share_queue(c, user, *slot);
-      for (int j = 0; j < k && !clash; ++j) {
-        hipStream_t other = j == 0 ? c->side : c->sidex[j - 1];
-        clash = streams_share_queue(c, *slot, other) || streams_share_queue(c, other, *slot);
-      }
-      if (!clash) break;
+      bool clash = streams_clash(w, *slot, user);
+      for (int j = 0; j < k && !clash; ++j) clash = streams_clash(w, *slot, j == 0 ? c->side : c->sidex[j - 1]);
+      bool clash_other = false;
+      for (size_t j = 0; j < others.size() && !clash && !clash_other; ++j) clash_other = streams_clash(w, *slot, others[j]);
+      if (!clash && !clash_other) break;
+      // (with the others' streams the four queues may simply be taken: after 4 candidates only collisions inside the context count)
+      if (!clash && attempt >= 3) break;
       if (attempt == 7) { left++; break; }
       hipStream_t fresh = nullptr;
-      EAE_HIP(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, c->side_prio));
+      EAE_HIP(eae_new_stream(&fresh, c->side_prio));
       drop.push_back(*slot);            // destroyed at the end: while it lives, the next candidate goes to another queue
       *slot = fresh;
       replaced++;
     }
   }
   for (hipStream_t st : drop) hipStreamDestroy(st);
-  if (mode >= 2) fprintf(stderr, "[eae] stream probe: %d side stream(s) replaced, %d still share a hardware queue\n", replaced, left);
+  reg.used.emplace_back(user, c);
+  for (int k = 0; k < ns; ++k) reg.used.emplace_back(k == 0 ? c->side : c->sidex[k - 1], c);
+  if (mode >= 2) fprintf(stderr, "[eae] stream probe: %d side stream(s) replaced, %d still share a hardware queue (%zu other streams in use)\n", replaced, left, others.size());
   return 0;
+}
+void streams_forget(const eae_ctx* c) {
+  StreamRegistry& reg = stream_registry();
+  std::lock_guard<std::mutex> lock(reg.mu);
+  for (size_t i = reg.used.size(); i-- > 0;) if (reg.used[i].second == c) reg.used.erase(reg.used.begin() + i);
 }
 
 unsigned* poison_word(const eae_ctx* c) { return reinterpret_cast<unsigned*>(c->acc_base + c->poison_off); }
@@ -1618,6 +1681,29 @@ int group_slot_of(void* ctx, hipStream_t user, hipStream_t st) {
 hipStream_t group_stream(eae_ctx* c, hipStream_t user, int slot) { return slot == 0 ? user : slot == 1 ? c->side : c->sidex[slot - 2]; }
 
 }  // namespace
+
+// Do two streams reach the GPU through the same hardware queue (1), through different ones (0)?  Synchronises the device; < 0: error.
+extern "C" int eae_streams_share_queue(void* a, void* b) {
+  static thread_local unsigned* w = nullptr;
+  static thread_local int w_dev = -1;
+  int dev = 0;
+  EAE_HIP(hipGetDevice(&dev));
+  if (!w || w_dev != dev) { EAE_HIP(hipMalloc(reinterpret_cast<void**>(&w), 64)); w_dev = dev; }      // (a few bytes per thread and device, kept)
+  StreamRegistry& reg = stream_registry();
+  std::lock_guard<std::mutex> lock(reg.mu);
+  EAE_HIP(hipDeviceSynchronize());
+  return streams_clash(w, (hipStream_t)a, (hipStream_t)b) ? 1 : 0;
+}
+// A driver that steps contexts from several threads reserves its worker streams (on = 1) before the first step: the contexts' side
+// streams then keep clear of them too.  on = 0 releases.
+extern "C" int eae_reserve_stream(void* stream, int on) {
+  StreamRegistry& reg = stream_registry();
+  std::lock_guard<std::mutex> lock(reg.mu);
+  for (size_t i = reg.used.size(); i-- > 0;)
+    if (reg.used[i].first == (hipStream_t)stream && reg.used[i].second == nullptr) reg.used.erase(reg.used.begin() + i);
+  if (on) reg.used.emplace_back((hipStream_t)stream, nullptr);
+  return 0;
+}
 
 extern "C" int eae_set_geometry_mult(int mult) {
   if (mult < 1 || mult > 64) return eae_set_error(EAE_ERR_ARG, "geometry_mult: 1..64");

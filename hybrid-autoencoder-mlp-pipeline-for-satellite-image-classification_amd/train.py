@@ -237,37 +237,106 @@ def fit_autoencoder_group(train_loader, val_loader, configs, latent_dim=64, num_
              "best_val_loss": best[k], "epochs": len(train_curve[k])} for k in range(n)]
 
 
-def run_concurrent(jobs, concurrent, device="cuda"):
+_WORKER_STREAMS = {}       # (device, workers) -> the worker streams run_concurrent picked (reused: a context re-checks its side streams per caller's stream)
+
+
+def run_concurrent(jobs, concurrent, device="cuda", static=False):
     """Run `jobs` (callables without arguments) on `concurrent` host threads, each with its OWN HIP stream current
     (torch.cuda.stream is thread-local), and return their results in job order.  This is how several small configurations share one
     GPU: at the reference's batch size 64 one train step is ~70 dependent launches of a few microseconds each, so a
     single stream leaves most of the 256 CUs idle and a single host thread cannot enqueue faster than the GPU drains; K engine contexts
-    (own workspace, own side streams) stepped from K threads -- ctypes releases the GIL inside every libeae call -- overlap both."""
+    (own workspace, own side streams) stepped from K threads -- ctypes releases the GIL inside every libeae call -- overlap both.
+    Worker k owns stream k and takes the next job when it is free; static=True: worker k runs jobs k, k + workers, ... (a job that is
+    submitted again in a later call then finds the same stream current, and its contexts need not re-check their side streams)."""
     import threading
-    from concurrent.futures import ThreadPoolExecutor
     dev = torch.device(device)
     if dev.type == "cuda" and not torch.cuda.is_available():
         dev = None
-    tls = threading.local()
+    nw = max(1, min(int(concurrent), len(jobs))) if jobs else 1
+    results, errors = [None] * len(jobs), []
+    nxt, nxt_lock = [0], threading.Lock()
 
-    def run(job):
-        if dev is None or dev.type != "cuda":
-            return job()
-        if not hasattr(tls, "stream"):
-            tls.stream = torch.cuda.Stream(device=dev)
-        with torch.cuda.device(dev), torch.cuda.stream(tls.stream):
-            out = job()
-            tls.stream.synchronize()
-        return out
+    def take(k):
+        if static:
+            yield from range(k, len(jobs), nw)
+            return
+        while True:
+            with nxt_lock:
+                i = nxt[0]
+                nxt[0] += 1
+            if i >= len(jobs):
+                return
+            yield i
+    if dev is None or dev.type != "cuda":
+        def cpu_worker(k):
+            for i in take(k):
+                try:
+                    results[i] = jobs[i]()
+                except BaseException as e:      # noqa: BLE001 -- re-raised below, in job order
+                    errors.append((i, e))
+        ths = [threading.Thread(target=cpu_worker, args=(k,)) for k in range(nw)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errors:
+            raise min(errors, key=lambda t: t[0])[1]
+        return results
+    # The workers' streams: ROCm multiplexes a process's streams onto 4 hardware queues, and two streams on one queue run one after the
+    # other.  Up to 4 workers get streams on pairwise DIFFERENT queues (candidates are drawn until they are: include/eae.h
+    # eae_streams_share_queue); the streams are announced to the engine so that the contexts' side streams avoid them too, and they are
+    # kept for the next call with the same number of workers (a context checks its side streams once per caller's stream).
+    from . import _lib
+    try:
+        lib = _lib.load()
+    except Exception:
+        lib = None
+    cache_key = (str(dev), int(concurrent))
+    picked = _WORKER_STREAMS.get(cache_key)
+    if picked is None:
+        picked = []
+        with torch.cuda.device(dev):
+            for _ in range(max(1, int(concurrent))):
+                cand = torch.cuda.Stream(device=dev)
+                if lib is not None and int(concurrent) <= 4:
+                    for _try in range(12):
+                        if not any(lib.eae_streams_share_queue(cand.cuda_stream, p.cuda_stream) == 1 for p in picked):
+                            break
+                        cand = torch.cuda.Stream(device=dev)
+                picked.append(cand)
+        _WORKER_STREAMS[cache_key] = picked
+    if lib is not None:
+        for st in picked[:nw]:
+            lib.eae_reserve_stream(st.cuda_stream, 1)
 
-    with ThreadPoolExecutor(max_workers=max(1, int(concurrent))) as ex:
-        return list(ex.map(run, jobs))
+    def worker(k):
+        st = picked[k]
+        with torch.cuda.device(dev), torch.cuda.stream(st):
+            for i in take(k):
+                try:
+                    results[i] = jobs[i]()
+                    st.synchronize()
+                except BaseException as e:      # noqa: BLE001 -- re-raised below, in job order
+                    errors.append((i, e))
+    try:
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(nw)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    finally:
+        if lib is not None:
+            for st in picked[:nw]:
+                lib.eae_reserve_stream(st.cuda_stream, 0)
+    if errors:
+        raise min(errors, key=lambda t: t[0])[1]
+    return results
 
 
 def grid_search_autoencoder(train_loader, val_loader, alpha_values=(20, 25, 30, 35, 40),
                             lr_values=(1e-4, 2e-4, 5e-4, 1e-3, 2e-3, 5e-3, 1e-2, 5e-2, 1e-1), latent_dim=64, num_epochs=80,
                             patience=15, out_dir="models_best", device="cuda", verbose=True, log=print, fit_fn=None, concurrent=1,
-                            grouped=0, group_fit_fn=None):
+                            grouped=0, group_fit_fn=None, concurrent_groups=1):
     """The reference's alpha x lr grid (R.md:599-729): trains every configuration, keeps the global best, writes
     `out_dir/AE_GLOBAL_BEST.pt` (plain state_dict) and `out_dir/validation_losses.json` (keys "alpha={a}, lr={lr}").
 
@@ -285,7 +354,13 @@ def grid_search_autoencoder(train_loader, val_loader, alpha_values=(20, 25, 30, 
     (bench.py `configs.grid_b64`) -- and the loaders are walked once per epoch for the whole group.  Each
     member's arithmetic is bitwise that of the configuration trained alone on the same batches with the group's tile geometries
     (tests/test_gpu_grid.py); what differs from the sequential grid is the data order when the loader shuffles: the members of a
-    group see the same permutation per epoch instead of consecutive draws from the generator."""
+    group see the same permutation per epoch instead of consecutive draws from the generator.
+
+    concurrent_groups=2 (with grouped=K) runs two groups at a time from two host threads (run_concurrent), every context with ONE side
+    stream: 2 x 2 streams are the GPU's four hardware queues, and one group's forward pass -- a chain of latency-bound kernels that
+    leaves most CUs idle -- runs beside the other group's backward pass (bench.py `configs.grid_b64`: 16 configurations at 0.89-0.92 M
+    images/s against 0.83-0.85 M for one group of 8).  The models are built in grid order on the calling thread, a configuration's
+    results do not depend on what runs beside it."""
     os.makedirs(out_dir, exist_ok=True)
     fit_fn = fit_fn or fit_autoencoder
     results, best = {}, {"loss": float("inf"), "info": None, "state": None, "train": None, "val": None}
@@ -293,17 +368,37 @@ def grid_search_autoencoder(train_loader, val_loader, alpha_values=(20, 25, 30, 
     fitted = None
     if grouped and int(grouped) > 1:
         gfit = group_fit_fn or fit_autoencoder_group
-        fitted = []
-        for g0 in range(0, len(grid), int(grouped)):
-            cfgs = grid[g0:g0 + int(grouped)]
-            lines = [[] for _ in cfgs]
-            rs = gfit(train_loader, val_loader, cfgs, latent_dim=latent_dim, num_epochs=num_epochs, patience=patience, device=device,
-                      verbose=verbose, logs=lines)
-            for r, ln in zip(rs, lines):
-                r = dict(r)
-                r["state"] = None if r.get("model") is None else {k: v.detach().cpu().clone() for k, v in r["model"].state_dict().items()}
-                r["model"] = None           # release the engine (workspace, streams) of a finished configuration
-                fitted.append((r, ln))
+        pairs = max(1, int(concurrent_groups or 1))
+        chunks = [grid[g0:g0 + int(grouped)] for g0 in range(0, len(grid), int(grouped))]
+        prebuilt = None
+        if pairs > 1 and gfit is fit_autoencoder_group:
+            # parameter initialisation draws from torch's global generator: in grid order, on this thread (as for `concurrent`)
+            prebuilt = []
+            for cfgs in chunks:
+                ms = [SupervisedAutoencoder(latent_dim=latent_dim, num_classes=10).to(device) for _ in cfgs]
+                for m in ms:
+                    m._eae_side_streams = 1          # two groups x (caller's stream + one side stream) = the four hardware queues
+                prebuilt.append(ms)
+
+        def group_job(gi):
+            def job():
+                cfgs = chunks[gi]
+                lines = [[] for _ in cfgs]
+                extra = {"models": prebuilt[gi]} if prebuilt is not None else {}
+                rs = gfit(train_loader, val_loader, cfgs, latent_dim=latent_dim, num_epochs=num_epochs, patience=patience, device=device,
+                          verbose=verbose, logs=lines, **extra)
+                out = []
+                for r, ln in zip(rs, lines):
+                    r = dict(r)
+                    r["state"] = None if r.get("model") is None else {k: v.detach().cpu().clone() for k, v in r["model"].state_dict().items()}
+                    r["model"] = None           # release the engine (workspace, streams) of a finished configuration
+                    out.append((r, ln))
+                if prebuilt is not None:
+                    prebuilt[gi] = None
+                return out
+            return job
+        done = run_concurrent([group_job(gi) for gi in range(len(chunks))], pairs, device) if pairs > 1 else [group_job(gi)() for gi in range(len(chunks))]
+        fitted = [item for chunk in done for item in chunk]
     elif concurrent and int(concurrent) > 1:
         # parameter initialisation draws from torch's global generator: K worker threads would draw in timing-dependent order
         prebuilt = {}

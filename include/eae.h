@@ -197,6 +197,14 @@ int eae_ae_train_step(eae_ctx* ctx, void* stream, const eae_step_io* io, float l
  * n <= 64; launches carry 8 members at a time. */
 int eae_group_train_step(eae_ctx* const* ctxs, int n, int geometry_mult, void* stream, const eae_step_io* ios, const float* lrs);
 int eae_group_forward(eae_ctx* const* ctxs, int n, int geometry_mult, void* stream, const eae_step_io* ios);
+/* Hardware queues.  ROCm multiplexes a process's streams onto 4 hardware queues and two streams on one queue run one after the other.
+ * Before its first step on a caller's stream a context checks its side streams against that stream, against each other and against
+ * every stream other contexts are stepping on, and replaces a side stream that collides (EAE_STREAM_PROBE=0: off, =2: verbose).
+ * eae_streams_share_queue: the same check for two arbitrary streams (1 = one queue, 0 = different ones; synchronises the device);
+ * eae_reserve_stream(stream, 1): a driver that steps contexts from several host threads announces its worker streams, so that the
+ * contexts' side streams keep clear of them too; (stream, 0) releases. */
+int eae_streams_share_queue(void* stream_a, void* stream_b);
+int eae_reserve_stream(void* stream, int on);
 /* Thread-local: launchers that choose a tile geometry or a grid by the size of the batch see batch * mult (1 = default).  Used by the
  * group-vs-alone parity tests; the group calls set it to their geometry_mult for their own duration. */
 int eae_set_geometry_mult(int mult);

@@ -175,3 +175,28 @@ def test_grouped_grid_is_bitwise_the_sequential_one_with_the_groups_geometries(t
     assert all(np.isfinite(v) for v in seq["results"].values())
     sa, sb = torch.load(seq["best_path"]), torch.load(grp["best_path"])
     assert all(torch.equal(sa[k], sb[k]) for k in sa)
+
+
+def test_two_concurrent_groups_are_bitwise_the_sequential_grid(tmp_path):
+    """grid_search_autoencoder(grouped=4, concurrent_groups=2): two groups of four step at the same time from two host threads, every
+    context with ONE side stream (2 x 2 streams = the four hardware queues).  A configuration's results do not depend on what runs
+    beside it, nor on the number of side streams: curves, winner and saved weights are bitwise those of the sequential grid run
+    with the groups' tile geometries."""
+    from eae_amd import _lib
+    from eae_amd import train as T
+    lib = _lib.load()
+    tr, va = _loaders()
+    kw = dict(alpha_values=(20, 25, 30, 35), lr_values=(1e-3, 5e-3), num_epochs=2, patience=15, verbose=True)
+    seq_log, par_log = [], []
+    torch.manual_seed(777)
+    _lib.check(lib.eae_set_geometry_mult(4))
+    try:
+        seq = T.grid_search_autoencoder(tr, va, out_dir=str(tmp_path / "seq"), log=seq_log.append, **kw)
+    finally:
+        _lib.check(lib.eae_set_geometry_mult(1))
+    torch.manual_seed(777)
+    par = T.grid_search_autoencoder(tr, va, out_dir=str(tmp_path / "par"), grouped=4, concurrent_groups=2, log=par_log.append, **kw)
+    assert seq["results"] == par["results"], (seq["results"], par["results"])
+    assert (seq["best_alpha"], seq["best_lr"]) == (par["best_alpha"], par["best_lr"]) and seq_log == par_log
+    sa, sb = torch.load(seq["best_path"]), torch.load(par["best_path"])
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)

@@ -173,6 +173,13 @@ def test_grid_search_grouped_same_bookkeeping_and_log_order(tmp_path):
     assert a["results"] == b["results"] and (a["best_alpha"], a["best_lr"]) == (b["best_alpha"], b["best_lr"]) == (40, 0.1)
     assert seq_logs == grp_logs
     assert json.load(open(tmp_path / "seq" / "validation_losses.json")) == json.load(open(tmp_path / "grp" / "validation_losses.json"))
+    # two groups at a time from two host threads: same bookkeeping, same log order
+    seen.clear()
+    par_logs = []
+    c = T.grid_search_autoencoder(None, None, alpha_values=(20, 30, 40), lr_values=(0.1, 0.2), out_dir=str(tmp_path / "par"), grouped=2,
+                                  concurrent_groups=2, group_fit_fn=fake_group_fit, log=par_logs.append, device="cpu")
+    assert sorted(seen) == [[(20, 0.1), (20, 0.2)], [(30, 0.1), (30, 0.2)], [(40, 0.1), (40, 0.2)]]
+    assert a["results"] == c["results"] and (c["best_alpha"], c["best_lr"]) == (40, 0.1) and par_logs == seq_logs
 
 
 class ScriptedMLP:
