@@ -239,32 +239,6 @@ extern "C" int eae_ae_layout(const eae_config* cfg, long long* param_off, long l
   return 0;
 }
 
-// A stream of the engine's own.  EAE_DEDICATED_QUEUES=1: created with a full CU mask -- ROCm gives such a stream a hardware queue of
-// its own instead of one of the 4 queues the process's other streams are multiplexed onto (experiment).
-static hipError_t eae_new_stream(hipStream_t* st, int prio) {
-  static const bool dedicated = getenv("EAE_DEDICATED_QUEUES") && atoi(getenv("EAE_DEDICATED_QUEUES")) != 0;
-  if (dedicated) {
-    int dev = 0; hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) {
-      const int ncu = pr.multiProcessorCount;
-      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-      for (int i = 0; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
-      if (hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()) == hipSuccess) return hipSuccess;
-    }
-  }
-  return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
-}
-extern "C" void* eae_stream_create_dedicated(void) {
-  hipStream_t st = nullptr;
-  int dev = 0; hipDeviceProp_t pr;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return nullptr;
-  const int ncu = pr.multiProcessorCount;
-  std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-  for (int i = 0; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
-  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) return nullptr;
-  return (void*)st;
-}
-
 extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   if (!out) return eae_set_error(EAE_ERR_ARG, "out is NULL");
   if (int rc = check_cfg(cfg)) return rc;
@@ -451,9 +425,9 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     const int side_prio = getenv("EAE_SIDE_PRIO_LOW") ? prio_lo : 0;
     c->side_prio = side_prio;
-    e = eae_new_stream(&c->side, side_prio);
+    e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, side_prio);
     for (int i = 0; i < c->nx && e == hipSuccess; ++i) {
-      e = eae_new_stream(&c->sidex[i], side_prio);
+      e = hipStreamCreateWithPriority(&c->sidex[i], hipStreamNonBlocking, side_prio);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_joinx[i], EV_FLAGS);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sx[i], EV_FLAGS);
     }
@@ -819,7 +793,7 @@ int streams_distinct(eae_ctx* c, hipStream_t user) {
       if (!clash && attempt >= 3) break;
       if (attempt == 7) { left++; break; }
       hipStream_t fresh = nullptr;
-      EAE_HIP(eae_new_stream(&fresh, c->side_prio));
+      EAE_HIP(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, c->side_prio));
       drop.push_back(*slot);            // destroyed at the end: while it lives, the next candidate goes to another queue
       *slot = fresh;
       replaced++;

@@ -1,3 +1,6 @@
+"""Which earlier work in the process slows the two-group leg of bench.py's grid measurement?  a = one context from a worker thread, b = four
+single-stream contexts from four threads, c = one group of 8 on the default stream, d = two groups of 8 from two threads; e.g.
+`python tools/grid_order_probe.py cd`.  Diagnostic tool (GPU box)."""
 import os, sys, time, gc, torch
 sys.path.insert(0, "/root/repo")
 import bench
@@ -5,12 +8,6 @@ import eae_amd
 from eae_amd.engine import AEEngine, engine_for
 from eae_amd import train as T
 order = sys.argv[1]
-if os.environ.get("GB_DEDICATED_WORKERS") == "1":          # worker streams with hardware queues of their own
-    import ctypes as C
-    from eae_amd import _lib
-    raw = C.CDLL(_lib.LIB_PATH); raw.eae_stream_create_dedicated.restype = C.c_void_p
-    for nw in (1, 2, 4):
-        T._WORKER_STREAMS[("cuda", nw)] = [torch.cuda.ExternalStream(raw.eae_stream_create_dedicated()) for _ in range(nw)]
 x, y = bench.make_batch(64, torch.device("cuda"), seed=4321)
 k = 8
 def single(kk, single_stream):
