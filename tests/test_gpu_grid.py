@@ -200,3 +200,29 @@ def test_two_concurrent_groups_are_bitwise_the_sequential_grid(tmp_path):
     assert (seq["best_alpha"], seq["best_lr"]) == (par["best_alpha"], par["best_lr"]) and seq_log == par_log
     sa, sb = torch.load(seq["best_path"]), torch.load(par["best_path"])
     assert all(torch.equal(sa[k], sb[k]) for k in sa)
+
+
+def test_hardware_queue_check_and_worker_streams():
+    """eae_streams_share_queue: a stream shares its queue with itself; run_concurrent's worker streams (<= 4 workers) sit on pairwise
+    different hardware queues and are the same objects in the next call with the same number of workers; reserving / releasing a
+    stream is accepted.  (ROCm multiplexes a process's streams onto 4 hardware queues: DESIGN.md section 6.)"""
+    from eae_amd import _lib
+    from eae_amd import train as T
+    lib = _lib.load()
+    s = torch.cuda.Stream()
+    assert lib.eae_streams_share_queue(s.cuda_stream, s.cuda_stream) == 1
+    assert lib.eae_reserve_stream(s.cuda_stream, 1) == 0 and lib.eae_reserve_stream(s.cuda_stream, 0) == 0
+    seen = []
+
+    def job():
+        seen.append(torch.cuda.current_stream().cuda_stream)
+        return len(seen)
+    T.run_concurrent([job, job, job], 3, static=True)
+    first = sorted(seen)
+    assert len(set(first)) == 3
+    for i in range(3):
+        for j in range(i + 1, 3):
+            assert lib.eae_streams_share_queue(first[i], first[j]) == 0, (i, j)
+    seen.clear()
+    T.run_concurrent([job, job, job], 3, static=True)
+    assert sorted(seen) == first
