@@ -292,6 +292,13 @@ __device__ __forceinline__ void fc_tn_body(const FcTnArgs& a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
   const int kg8 = tid & 7;
+  // out_mode 1 (enc.fc's weight gradient: columns permuted j' = p*256 + c -> c*Pn + p): the 64 columns of a tile are 16 consecutive channels
+  // at 4 consecutive positions (column jl <-> position p0 + jl/16, channel c0 + jl%16) instead of 64 consecutive channels at one position,
+  // so a lane's four accumulator tiles are four CONSECUTIVE output floats and the epilogue writes one 16-byte piece per row instead
+  // of four 4-byte ones Pn floats apart (256x256 inputs: 141 us for this kernel, a 67 MB fp32 output written 4 bytes per KB).
+  const bool pj = a.out_mode == 1 && (a.Pn & 3) == 0 && a.J == 256 * a.Pn;
+  const int pj_c0 = (blockIdx.y & 15) * 16, pj_p0 = (blockIdx.y >> 4) * 4;
+  const int qcol = pj ? (pj_p0 + (kg8 >> 1)) * 256 + pj_c0 + (kg8 & 1) * 8 : j0 + kg8 * 8;       // first of this thread's 8 Q columns
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
   f32x4 acc[4];
 #pragma unroll
@@ -305,7 +312,7 @@ __device__ __forceinline__ void fc_tn_body(const FcTnArgs& a) {
   for (int j = 0; j < 8; ++j) {
     pcs[j] = pct[j] = qcs[j] = qct[j] = 0.f;
     if (PMODE == SRC_BNRELU) { const int ch = ((i0 + kg8 * 8) & 255) + j; pcs[j] = a.p.coef[ch]; pct[j] = a.p.coef[256 + ch]; }
-    if (QMODE == SRC_BNRELU) { const int ch = ((j0 + kg8 * 8) & 255) + j; qcs[j] = a.q.coef[ch]; qct[j] = a.q.coef[256 + ch]; }
+    if (QMODE == SRC_BNRELU) { const int ch = (qcol & 255) + j; qcs[j] = a.q.coef[ch]; qct[j] = a.q.coef[256 + ch]; }
   }
   const int nchunks = (a.Bt + 63) / 64;
   FcRaw<PMODE> rp[FC_TN_D][2];
@@ -317,7 +324,7 @@ __device__ __forceinline__ void fc_tn_body(const FcTnArgs& a) {
       int row = b0 + ((tid + i * 256) >> 3);
       row = row < a.Bt ? row : a.Bt - 1;                          // clamped: the load is unconditional, the value is zeroed in fc_finish_raw
       fc_load_raw<PMODE>(a.p, (size_t)row * a.I + i0 + kg8 * 8, xp[i]);
-      fc_load_raw<QMODE>(a.q, (size_t)row * a.J + j0 + kg8 * 8, xq[i]);
+      fc_load_raw<QMODE>(a.q, (size_t)row * a.J + qcol, xq[i]);
     }
   };
 #pragma unroll
@@ -357,15 +364,24 @@ __device__ __forceinline__ void fc_tn_body(const FcTnArgs& a) {
   }
   const int Pn = a.Pn;
   auto perm = [=](int k2) -> int { return (k2 & 255) * Pn + (k2 >> 8); };
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
+  if (pj) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int i = i0 + wave * 16 + (lane >> 4) * 4 + r;
-      int j = j0 + jt * 16 + (lane & 15);
-      size_t o = (a.out_mode == 0) ? (size_t)perm(i) * a.J + j : (size_t)i * a.J + perm(j);
-      a.out[o] = acc[jt][r];
+      const int i = i0 + wave * 16 + (lane >> 4) * 4 + r;
+      const size_t o = (size_t)i * a.J + (size_t)(pj_c0 + (lane & 15)) * Pn + pj_p0;
+      *reinterpret_cast<float4*>(a.out + o) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
     }
+  } else {
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int i = i0 + wave * 16 + (lane >> 4) * 4 + r;
+        int j = j0 + jt * 16 + (lane & 15);
+        size_t o = (a.out_mode == 0) ? (size_t)perm(i) * a.J + j : (size_t)i * a.J + perm(j);
+        a.out[o] = acc[jt][r];
+      }
+  }
   if (a.colsum && blockIdx.y == 0) {
     // thread (row-group tid>>3, chunk kg8) holds partial column sums of its rows; reduce over the 32 row-groups
     __syncthreads();
