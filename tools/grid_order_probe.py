@@ -1,5 +1,5 @@
 """Which earlier work in the process slows the two-group leg of bench.py's grid measurement?  a = one context from a worker thread, b = four
-single-stream contexts from four threads, c = one group of 8 on the default stream, d = two groups of 8 from two threads; e.g.
+single-stream contexts from four threads, c = one group of 8 on the default stream, d = two groups of 8 from two threads, e = the same for 10 steps only; e.g.
 `python tools/grid_order_probe.py cd`.  Diagnostic tool (GPU box)."""
 import os, sys, time, gc, torch
 sys.path.insert(0, "/root/repo")
@@ -25,7 +25,7 @@ def single(kk, single_stream):
     t0 = time.perf_counter(); T.run_concurrent([job_of(e, 150) for _, e in engs], kk, static=True); torch.cuda.synchronize()
     print("single", kk, round(kk * 150 * 64 / (time.perf_counter() - t0)), flush=True)
     del engs; gc.collect(); torch.cuda.empty_cache()
-def grouped(ng, ss):
+def grouped(ng, ss, nsteps=150):
     groups = []
     for g in range(ng):
         es = []
@@ -44,9 +44,9 @@ def grouped(ng, ss):
         gjob(groups[0], 15)(); torch.cuda.synchronize(); t0 = time.perf_counter(); gjob(groups[0], 150)()
     else:
         T.run_concurrent([gjob(es, 15) for es in groups], ng, static=True); torch.cuda.synchronize()
-        t0 = time.perf_counter(); T.run_concurrent([gjob(es, 150) for es in groups], ng, static=True)
+        t0 = time.perf_counter(); T.run_concurrent([gjob(es, nsteps) for es in groups], ng, static=True)
     torch.cuda.synchronize()
-    print("grouped", ng, ss, round(ng * k * 150 * 64 / (time.perf_counter() - t0)), flush=True)
+    print("grouped", ng, ss, nsteps, round(ng * k * nsteps * 64 / (time.perf_counter() - t0)), flush=True)
     del groups; gc.collect(); torch.cuda.empty_cache()
 for ch in order:
-    {"a": lambda: single(1, False), "b": lambda: single(4, True), "c": lambda: grouped(1, 0), "d": lambda: grouped(2, 1)}[ch]()
+    {"a": lambda: single(1, False), "b": lambda: single(4, True), "c": lambda: grouped(1, 0), "d": lambda: grouped(2, 1), "e": lambda: grouped(2, 1, 10)}[ch]()
