@@ -220,9 +220,8 @@ def grid_b64_leg(k=int(os.environ.get("EAE_GRID_K", "8")), steps=150, warmup=15)
         torch.cuda.empty_cache()
         return out
     # what grid_search_autoencoder(grouped=K, concurrent_groups=2) does: two groups at a time from two host threads, one side stream per
-    # context (2 x 2 streams = the four hardware queues; one group's forward beside the other's backward) -- measured FIRST: which
-    # hardware queue a stream gets depends on the streams the process created before, and this leg is the one that needs all four
-    # (DESIGN.md section 6); then one group of K with the default stream layout
+    # context (2 x 2 streams = the four hardware queues; one group's forward beside the other's backward); then one group of K with
+    # the default stream layout
     res["grouped"] = grouped_leg(2, 1)
     res["grouped_one"] = grouped_leg(1, 0)
     for name, kk in (("k1", 1), ("concurrent", 4)):
@@ -249,25 +248,6 @@ def grid_b64_leg(k=int(os.environ.get("EAE_GRID_K", "8")), steps=150, warmup=15)
     return res
 
 
-def grid_b64_in_child():
-    """grid_b64_leg in a fresh child process -- a grid search is a process of its own, and the hardware queues its streams get depend on
-    the streams the process created before (after this process's headline / c2 / c5 legs the two-group leg measures 0.70 instead of
-    0.92 M images/s: DESIGN.md section 6).  Falls back to measuring in this process."""
-    import subprocess
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "gridleg"], capture_output=True, text=True, timeout=600)
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("GRIDLEG ")]
-        if r.returncode == 0 and line:
-            res = json.loads(line[-1][8:])
-            res["process"] = "fresh child process (python bench.py --workload gridleg)"
-            return res
-    except Exception:
-        pass
-    res = grid_b64_leg()
-    res["process"] = "this process (the child process failed)"
-    return res
-
-
 C2_WORKLOAD = "BASELINE configs[1]: batch 256, encoder+decoder reconstruction (MSE) only, bf16"
 
 
@@ -276,10 +256,6 @@ def side_workload(args, device):
     tools/profile_round.sh can put rocprofv3 around it (kernel stats + PMC passes per workload) and the line carries its roofline."""
     import eae_amd
     from eae_amd.engine import engine_for
-    if args.workload == "gridleg":
-        # the whole configs.grid_b64 measurement in a process of its own (bench.py's default run starts it as a child)
-        print("GRIDLEG " + json.dumps(grid_b64_leg()), flush=True)
-        return
     if args.workload == "grid8":
         # the notebook's own batch size, eight grid configurations stepped as one group (configs.grid_b64's grouped leg, alone, for rocprofv3)
         from eae_amd.engine import AEEngine
@@ -341,7 +317,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configs[1] measurement")
-    ap.add_argument("--workload", choices=("c3", "c2", "c5fp8", "c5bf16", "grid8", "gridleg"), default="c3",
+    ap.add_argument("--workload", choices=("c3", "c2", "c5fp8", "c5bf16", "grid8"), default="c3",
                     help="c3 = BASELINE configs[2], the headline (default); the others run the same loop over configs[1] / configs[4]'s shape")
     args = ap.parse_args()
 
@@ -467,7 +443,7 @@ def main():
             except Exception as e:
                 out.setdefault("configs", {})["c5"] = {"error": str(e)[:200]}
             try:
-                out.setdefault("configs", {})["grid_b64"] = grid_b64_in_child()
+                out.setdefault("configs", {})["grid_b64"] = grid_b64_leg()
                 out["configs"]["grid_b64"]["vs_b512_single_model"] = round(out["configs"]["grid_b64"]["images_per_s"] / value, 3)
             except Exception as e:
                 out.setdefault("configs", {})["grid_b64"] = {"error": str(e)[:200]}

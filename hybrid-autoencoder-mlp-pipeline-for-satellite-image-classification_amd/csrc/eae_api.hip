@@ -733,7 +733,7 @@ int join_side(eae_ctx* c, hipStream_t st) {
 // contexts from worker threads before; bench.py's grid leg).  Checked once per (context, caller's stream) before the first step:
 // a gate on stream A waits (bounded, 0.3 ms) for a word that a kernel enqueued AFTERWARDS on stream B publishes -- it times out exactly
 // when B's kernel cannot start beside it.  A side stream that collides is replaced by a fresh one (created while the colliding one
-// is still alive, so it lands elsewhere), up to 8 candidates.  EAE_STREAM_PROBE=0 switches the check off, =2 reports what it found.
+// is still alive, so it lands elsewhere), up to 16 candidates.  EAE_STREAM_PROBE=0 switches the check off, =2 reports what it found.
 // ---------------------------------------------------------------------------------------------------------------------
 // (two device words: [0] the word the gate waits for, [1] its time-out flag -- not the sticky word the optimizer looks at)
 bool streams_share_queue(unsigned* w, hipStream_t a, hipStream_t b) {
@@ -779,19 +779,21 @@ int streams_distinct(eae_ctx* c, hipStream_t user) {
     others.push_back(u.first);
   }
   const int ns = 1 + c->nx;
-  int replaced = 0, left = 0;
+  int replaced = 0, left = 0, left_other = 0;
   std::vector<hipStream_t> drop;
   for (int k = 0; k < ns; ++k) {
     hipStream_t* slot = k == 0 ? &c->side : &c->sidex[k - 1];
-    for (int attempt = 0; attempt < 8; ++attempt) {
+    for (int attempt = 0; attempt < 16; ++attempt) {
       bool clash = streams_clash(w, *slot, user);
       for (int j = 0; j < k && !clash; ++j) clash = streams_clash(w, *slot, j == 0 ? c->side : c->sidex[j - 1]);
       bool clash_other = false;
       for (size_t j = 0; j < others.size() && !clash && !clash_other; ++j) clash_other = streams_clash(w, *slot, others[j]);
       if (!clash && !clash_other) break;
-      // (with the others' streams the four queues may simply be taken: after 4 candidates only collisions inside the context count)
-      if (!clash && attempt >= 3) break;
-      if (attempt == 7) { left++; break; }
+      // (with the others' streams the four queues may simply be taken: after 12 candidates only collisions inside the context count.
+      //  Four were not enough: two groups stepped from two threads need the ONE queue the other three streams leave free, and the
+      //  runs in which the second group gave up early measured 0.72 instead of 0.94 M images/s)
+      if (!clash && attempt >= 11) { left_other++; break; }
+      if (attempt == 15) { left++; break; }
       hipStream_t fresh = nullptr;
       EAE_HIP(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, c->side_prio));
       drop.push_back(*slot);            // destroyed at the end: while it lives, the next candidate goes to another queue
@@ -802,7 +804,7 @@ int streams_distinct(eae_ctx* c, hipStream_t user) {
   for (hipStream_t st : drop) hipStreamDestroy(st);
   reg.used.emplace_back(user, c);
   for (int k = 0; k < ns; ++k) reg.used.emplace_back(k == 0 ? c->side : c->sidex[k - 1], c);
-  if (mode >= 2) fprintf(stderr, "[eae] stream probe: %d side stream(s) replaced, %d still share a hardware queue (%zu other streams in use)\n", replaced, left, others.size());
+  if (mode >= 2) fprintf(stderr, "[eae] stream probe: %d side stream(s) replaced, %d still share a hardware queue inside the context, %d with another context's (%zu other streams in use)\n", replaced, left, left_other, others.size());
   return 0;
 }
 void streams_forget(const eae_ctx* c) {
