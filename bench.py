@@ -213,7 +213,7 @@ def grid_b64_leg(k=int(os.environ.get("EAE_GRID_K", "8")), steps=150, warmup=15)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         out = {"groups": ngroups, "configs": ngroups * k, "steps_each": steps, "images_per_s": round(ngroups * k * steps * 64 / el, 1),
-               "ms_per_round_of_group_steps": round(1e3 * el / steps, 4), "side_streams_per_context": side_streams or 2,
+               "ms_per_round_of_group_steps": round(1e3 * el / steps, 4), "side_streams_per_context": side_streams,
                "gate_timeouts": sum(1 for es in groups for _, e in es if e.gate_timeouts())}
         del groups
         gc.collect()                # (engine contexts sit in reference cycles: destroy them, and their claims on hardware queues, now)
@@ -223,7 +223,7 @@ def grid_b64_leg(k=int(os.environ.get("EAE_GRID_K", "8")), steps=150, warmup=15)
     # context (2 x 2 streams = the four hardware queues; one group's forward beside the other's backward); then one group of K with
     # the default stream layout
     res["grouped"] = grouped_leg(2, 1)
-    res["grouped_one"] = grouped_leg(1, 0)
+    res["grouped_one"] = grouped_leg(1, 2)
     for name, kk in (("k1", 1), ("concurrent", 4)):
         engs = build(kk, kk >= 3)
 

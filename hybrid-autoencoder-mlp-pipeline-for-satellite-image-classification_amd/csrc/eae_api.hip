@@ -275,8 +275,12 @@ extern "C" int eae_create(const eae_config* cfg, eae_ctx** out) {
   c->wscratch_floats = 6LL * 1024 * 1024;    // 24 MB of fp32 split-K partials
   size_t o_wscr = carve(c->wscratch_floats * 4), o_wscrx[eae_ctx::MAXX];
   {
+    // Three side streams + the caller's stream = the GPU's four hardware queues (round 4: 0.4655 vs 0.4731 ms per B=512 step with two,
+    // 0.505 with four -- five streams on four queues; c2 0.322 vs 0.326, config-5 shape unchanged).  Rounds 1-3 measured no gain from a
+    // third one: its queue was whichever the runtime handed out, often the caller's (streams_distinct below now checks and repairs).
+    // Grouped steps keep two (train.py: 0.596 vs 0.604 ms per group step), concurrent groups one each.
     const char* e = getenv("EAE_SIDE_STREAMS");
-    int ns = e ? atoi(e) : 2;
+    int ns = e ? atoi(e) : 3;
     if (cfg->side_streams > 0) ns = cfg->side_streams;
     c->nx = ns < 1 ? 0 : (ns - 1 > eae_ctx::MAXX ? eae_ctx::MAXX : ns - 1);
     if (getenv("EAE_ONE_SIDE_STREAM")) c->nx = 0;

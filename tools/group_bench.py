@@ -31,6 +31,8 @@ for k in ks:
     for i in range(k):
         torch.manual_seed(100 + i)
         m = eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=10).cuda().train()
+        if "EAE_SIDE_STREAMS" not in os.environ:
+            m._eae_side_streams = 2          # what train.fit_autoencoder_group builds
         engs.append((m, engine_for(m, max_batch=B)))
     es = [e for _, e in engs]
     xs, ys, al, lr = [x] * k, [y] * k, [35.0] * k, [1e-3] * k
