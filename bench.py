@@ -263,6 +263,7 @@ def side_workload(args, device):
         for i in range(8):
             torch.manual_seed(100 + i)
             m = eae_amd.SupervisedAutoencoder(latent_dim=64, num_classes=10).to(device).train()
+            m._eae_side_streams = 2               # what train.fit_autoencoder_group builds (a grouped step is fastest with two)
             engs.append((m, engine_for(m, max_batch=64)))
         es = [e for _, e in engs]
         x, y = make_batch(64, device, seed=4321)
